@@ -1,0 +1,36 @@
+# Builds the in-tree artefacts: the render-path library (HIP, gfx950), the `run` CLI and the
+# CPU oracle used by the tests.  hipcc cross-compiles gfx950 without a GPU present.
+HIPCC    ?= /opt/rocm/bin/hipcc
+CXX      ?= g++
+ARCH     ?= gfx950
+CSRC     := raytracer_amd/csrc
+# -ffp-contract=off everywhere: the reference arithmetic has no fused multiply-adds and the
+# accept/reject decisions of the traversal are compared bit for bit.
+HOSTFLAGS := -std=c++17 -O2 -ffp-contract=off -fPIC -Wall -Wno-unused-function -Iinclude
+HIPFLAGS  := -std=c++17 -O3 -ffp-contract=off -fPIC --offload-arch=$(ARCH) -Wall -Wno-unused-function -Iinclude
+
+LIB := raytracer_amd/librt_amd.so
+RUN := raytracer_amd/run
+
+all: $(LIB) $(RUN) oracle
+
+$(CSRC)/rt_host.o: $(CSRC)/rt_host.cpp $(CSRC)/rt_internal.h include/rt_amd.h
+	$(CXX) $(HOSTFLAGS) -c $< -o $@
+
+$(CSRC)/rt_device.o: $(CSRC)/rt_device.hip $(CSRC)/rt_internal.h $(CSRC)/rt_math.h include/rt_amd.h
+	$(HIPCC) $(HIPFLAGS) -c $< -o $@
+
+$(LIB): $(CSRC)/rt_host.o $(CSRC)/rt_device.o
+	$(HIPCC) --offload-arch=$(ARCH) -shared -fPIC -o $@ $^
+
+$(RUN): $(CSRC)/run_main.cpp $(LIB) include/rt_amd.h
+	$(CXX) $(HOSTFLAGS) $< -o $@ -Lraytracer_amd -lrt_amd -Wl,-rpath,'$$ORIGIN'
+
+oracle:
+	$(MAKE) -C oracle
+
+clean:
+	rm -f $(CSRC)/*.o $(LIB) $(RUN)
+	$(MAKE) -C oracle clean
+
+.PHONY: all oracle clean

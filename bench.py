@@ -1,0 +1,182 @@
+#!/usr/bin/env python3
+"""Headline benchmark: Mrays/s on scenes/meshDragon.json at 3840x2160 (max depth 3), N GPUs of one node.
+
+One step = one full frame.  With N > 1 the frame is cut into 16-row bands dealt round-robin to the
+ranks (one process per GPU); every rank renders its bands packed and a single RCCL gather collects
+the framebuffer tiles on rank 0 (total work fixed: strong scaling).  Inputs are resident in HBM
+before the timed region; the output stays on the device.
+
+  python bench.py --gpus 1 --steps 20 --warmup 3
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+      bench.py --gpus N --steps K --warmup W
+
+Rank 0 prints one JSON line.  `rays` are calls of the closest-hit routine the reference performs for
+the frame (primary + shadow + bounce); the kernels report the same count from their own counters.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+BAND_ROWS = 16
+PEAK_FP32_TFLOPS = 157.3     # MI355X vector FP32 peak (256 CU x 4 SIMD x 64 FLOP/clk x 2.4 GHz)
+PEAK_HBM_GBS = 8000.0
+
+# Algorithmic work per test of the minimal equivalent formulation (slab node test, the reference's
+# Cramer triangle solve, sphere quadratic, shading per ray): FLOP.
+F_NODE, F_TRI, F_SPH, F_SHADE = 24, 61, 20, 150
+# Algorithmic bytes: node record, triangle reference + positions, hit normals + ray record.
+B_NODE, B_TRI, B_RAY = 32, 40, 136
+
+
+def parse_args():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--scene", default="scenes/meshDragon.json")
+    ap.add_argument("--width", type=int, default=3840)
+    ap.add_argument("--height", type=int, default=2160)
+    ap.add_argument("--depth", type=int, default=3)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-band-stride", type=int, default=4, help="oracle renders every k-th 16-row band")
+    return ap.parse_args()
+
+
+def cpu_baseline(args, threads):
+    """Time the CPU oracle on every k-th 16-row band of the same frame (a bounded, representative sample)."""
+    from oracle_api import OracleScene
+    o = OracleScene(args.scene, args.width, args.height, args.depth)
+    import numpy as np
+    import ctypes as C
+    from oracle_api import Counters, lib
+    rgb = np.zeros((args.height, args.width, 3), np.uint8)
+    rays = 0
+    rows = 0
+    t0 = time.perf_counter()
+    for b in range(0, (args.height + BAND_ROWS - 1) // BAND_ROWS, args.cpu_band_stride):
+        ct = Counters()
+        r0, r1 = b * BAND_ROWS, min((b + 1) * BAND_ROWS, args.height)
+        lib().oracle_render_rows(o.h, r0, r1, rgb.ctypes.data, None, None, C.byref(ct), threads)
+        rays += ct.rays
+        rows += r1 - r0
+    dt = time.perf_counter() - t0
+    return {"value": rays / dt / 1e6, "unit": "Mrays/s", "cores": threads, "kind": "port",
+            "sample": "every %d-th 16-row band of the same %dx%d frame: %d rows, %d rays in %.2f s" %
+                      (args.cpu_band_stride, args.width, args.height, rows, rays, dt)}
+
+
+def main():
+    args = parse_args()
+    import torch
+    import torch.distributed as dist
+    import raytracer_amd as rt
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("bench.py --gpus %d must be launched with torch.distributed.run (one rank per GPU)" % args.gpus)
+        raise SystemExit("WORLD_SIZE=%d does not match --gpus %d" % (world, args.gpus))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the render path has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        dist.init_process_group("nccl", device_id=dev)
+
+    W, H = args.width, args.height
+    scene = rt.Scene(args.scene, W, H, args.depth)
+    info = scene.info()
+    ds = rt.DeviceScene(scene, device=local_rank)
+    nb_max = ds.band_count(BAND_ROWS, 0, world)            # rank 0 owns the most bands
+    local = torch.zeros((nb_max * BAND_ROWS, W, 3), dtype=torch.uint8, device=dev)
+    gathered = [torch.zeros_like(local) for _ in range(world)] if (world > 1 and rank == 0) else None
+    stream = torch.cuda.current_stream()
+
+    def step(flags=0, want_stats=False):
+        st = ds.render_bands_into(local.data_ptr(), BAND_ROWS, rank, world, stream=stream.cuda_stream, flags=flags,
+                                  want_stats=want_stats)
+        if world > 1:
+            dist.gather(local, gathered, dst=0)
+        return st
+
+    # ray counts of this rank's share (deterministic; read back once, outside the timed region)
+    st = step(want_stats=True)
+    rays_t = torch.tensor([st["rays"], st["shadow_rays"]], dtype=torch.int64, device=dev)
+    if world > 1:
+        dist.all_reduce(rays_t)
+    rays_total, shadow_total = int(rays_t[0]), int(rays_t[1])
+
+    for _ in range(args.warmup):
+        step()
+    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for k in range(args.steps):
+        ev[k][0].record(stream)
+        ds.render_bands_into(local.data_ptr(), BAND_ROWS, rank, world, stream=stream.cuda_stream)
+        ev[k][1].record(stream)
+        if world > 1:
+            dist.gather(local, gathered, dst=0)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    elapsed = time.perf_counter() - t0
+    kernel_ms = sum(a.elapsed_time(b) for a, b in ev) / max(args.steps, 1)
+    tt = torch.tensor([elapsed, kernel_ms], dtype=torch.float64, device=dev)
+    if world > 1:
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+    elapsed, kernel_ms = float(tt[0]), float(tt[1])
+
+    if rank == 0:
+        ms_per_step = elapsed * 1e3 / args.steps
+        mrays = rays_total / (elapsed / args.steps) / 1e6
+        # roofline of the dominant (only) kernel, from the reference's test counts for this exact frame
+        ref = None
+        try:
+            with open(os.path.join(ROOT, "tests", "golden", "reference_counters.json")) as f:
+                g = json.load(f)
+            key = "meshDragon_%dx%d" % (W, H)
+            if args.scene.endswith("meshDragon.json") and args.depth == 3 and key in g:
+                ref = g[key]
+        except OSError:
+            pass
+        roofline = None
+        if ref and ref["rays"] == rays_total:
+            flop = ref["node_tests"] * F_NODE + ref["tri_tests"] * F_TRI + ref["sphere_tests"] * F_SPH + ref["rays"] * F_SHADE
+            byts = ref["node_tests"] * B_NODE + ref["tri_tests"] * B_TRI + ref["rays"] * B_RAY
+            ach = flop / world / (kernel_ms * 1e-3) / 1e12     # per launch: this rank's share of the frame
+            roofline = {"bound": "valu_fp32", "achieved": ach, "peak": PEAK_FP32_TFLOPS, "unit": "TFLOP/s",
+                        "frac": ach / PEAK_FP32_TFLOPS, "traffic": None,
+                        "kernel": "render_tiles", "kernel_ms": kernel_ms, "flop_per_ray": flop / ref["rays"],
+                        "algorithmic_GBps": byts / world / (kernel_ms * 1e-3) / 1e9, "hbm_peak_GBps": PEAK_HBM_GBS}
+        out = {
+            "metric": "Mrays/s at 3840x2160 meshDragon", "value": mrays, "unit": "Mrays/s", "n_gpus": world,
+            "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step, "higher_is_better": True,
+            "scaling": "strong", "vs_baseline": None, "dtype": "f32",
+            "data": "the reference's own scene and mesh files (deterministic, no RNG anywhere in the path)",
+            "config": {"workload": "%s %dx%d depth %d" % (args.scene, W, H, args.depth), "rays_per_frame": rays_total,
+                       "shadow_rays_per_frame": shadow_total, "triangles": info["n_triangles"], "octree_nodes": info["n_nodes"],
+                       "partition": "%d-row bands round-robin over %d GPU(s), one RCCL gather" % (BAND_ROWS, world),
+                       "library": rt.version()},
+            "roofline": roofline,
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            threads = min(int(os.environ.get("OMP_NUM_THREADS", "0")) or (os.cpu_count() or 1), 16)
+            out["cpu_baseline"] = cpu_baseline(args, threads)
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,136 @@
+/* rt_amd.h -- C ABI of the MI355X render path (librt_amd.so).
+ *
+ * This is the drop-in boundary for the per-pixel render path of
+ * masotrix/raytracer.  The reference has no plugin API: its path sits behind
+ * the `run -s <scene>` command line + scene files on one side and the single
+ * kernel launch `film<<<blocks,128>>>(img, DCamera*, DLights*, DSpheres*,
+ * DOctTree*)` (main.cu:48-49, camera.cuh:52-53) on the other.  Each entry point
+ * below names the reference code it replaces.
+ *
+ * Conventions: every function returns RT_OK (0) or a negative rt_status;
+ * rt_strerror() gives the text and rt_last_error() the detail of the last
+ * failure on the calling thread.  No C++ exceptions cross this boundary.
+ * Handles are thread-compatible (one thread at a time per handle).
+ * Image layout is the reference's: W*H*3 bytes, RGB8, row 0 = top row
+ * (camera.cu:118-122).
+ */
+#ifndef RT_AMD_H
+#define RT_AMD_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef enum rt_status {
+  RT_OK = 0,
+  RT_ERR_ARG = -1,      /* bad argument (NULL handle, rows outside the image, ...) */
+  RT_ERR_IO = -2,       /* file missing / unreadable */
+  RT_ERR_PARSE = -3,    /* malformed JSON / OBJ, unknown material name */
+  RT_ERR_LIMIT = -4,    /* scene exceeds a fixed limit (octree deeper than 20, ray depth > 9, ...) */
+  RT_ERR_DEVICE = -5,   /* HIP call failed or no MI355X-class device */
+  RT_ERR_NOMEM = -6
+} rt_status;
+
+typedef struct rt_scene rt_scene;     /* host scene: parsed, transformed, octree built and flattened */
+typedef struct rt_dscene rt_dscene;   /* the same scene resident in one GPU's HBM */
+
+/* Primitive id written per pixel: triangle = global triangle index (meshes in
+ * scene order, faces in file order: mesh.cu:116-134), sphere s = -2 - s
+ * (index in scene order: object.cu:16-20), miss = -1. */
+#define RT_ID_MISS (-1)
+#define RT_ID_SPHERE(s) (-2 - (s))
+
+typedef struct rt_scene_info {
+  int32_t width, height, max_depth;
+  int32_t n_triangles, n_spheres, n_lights, n_materials;
+  int32_t n_nodes, n_leaves, n_empty_leaves, n_leaf_refs, tree_depth, max_leaf_size;
+  int32_t has_bounce_materials;  /* any reflective / dielectric material in use */
+  int32_t shadows_enabled;
+  double build_seconds;          /* octree construction + flattening */
+  double parse_seconds;          /* JSON + OBJ ingest + transforms */
+} rt_scene_info;
+
+/* Work counters of one render call.  rays = calls of the closest-hit routine
+ * (primary + bounce + shadow), the unit of the Mrays/s metric.  The four
+ * *_tests counters are only filled by rt_render_rows when RT_RENDER_COUNT_TESTS
+ * is set (instrumented kernel variant). */
+typedef struct rt_stats {
+  uint64_t rays, shadow_rays;
+  uint64_t node_tests, leaf_visits, tri_tests, sphere_tests;
+  uint64_t ub_leave_level0, ub_level_overflow, ub_stack_overflow;
+  float kernel_ms;   /* HIP-event time of the render kernels of this call (0 unless RT_RENDER_TIME) */
+} rt_stats;
+
+enum {
+  RT_RENDER_COUNT_TESTS = 1,  /* run the instrumented variant that counts node / leaf / triangle / sphere tests */
+  RT_RENDER_TIME = 2          /* bracket the kernels with HIP events on `stream` and synchronise */
+};
+
+/* Parse resources + scene, load and transform meshes, build the octree.
+ * Replaces parse() (parsing/parsing.cu:145-473) and main.cu:20-32.
+ * Mesh paths inside the scene are resolved against `base_dir` (NULL or "" =
+ * the process working directory, which is what the reference does). */
+int rt_scene_load(const char* scene_json, const char* resources_json, const char* base_dir,
+                  int width, int height, int max_depth, rt_scene** out);
+void rt_scene_destroy(rt_scene* s);
+int rt_scene_get_info(const rt_scene* s, rt_scene_info* out);
+
+/* Octree in depth-first preorder (children 0..7), the order
+ * OctBranch::buildDNodes walks (octtree/octtree.cu:64-87).  kind[i] = -1 for a
+ * branch else the leaf's triangle count; bounds[i*6..] = ini xyz, end xyz;
+ * refs = concatenated leaf contents in that order.  Buffers are sized from
+ * rt_scene_info (n_nodes, n_nodes*6, n_leaf_refs). */
+int rt_scene_dump_tree(const rt_scene* s, int32_t* kind, float* bounds, int32_t* refs);
+/* Triangles as uploaded by Mesh::buildDTriangles (mesh/mesh.cu:65-97):
+ * verts n*9, normals n*9, mesh index n. */
+int rt_scene_dump_triangles(const rt_scene* s, float* verts, float* normals, int32_t* mesh);
+/* DCamera fields (camera/camera.cu:45-74): u v w pos (12 floats), left right bottom top, bg rgb. */
+int rt_scene_dump_camera(const rt_scene* s, float* out19);
+
+/* Copy the flattened scene into HBM of HIP device `device`.
+ * Replaces the *GPUAdapter constructors (main.cu:20-23,32; one flat upload
+ * instead of one cudaMalloc per object). */
+int rt_scene_upload(const rt_scene* s, int device, rt_dscene** out);
+void rt_dscene_destroy(rt_dscene* d);
+
+/* Render image rows [row_begin,row_end) (row 0 = top).  Replaces the film
+ * launch + cudaDeviceSynchronize (main.cu:38-54).
+ *   d_rgb : DEVICE pointer to a full W*H*3 image; only the rows asked for are written.
+ *   d_ids : optional DEVICE pointer, W*H int32 primary-hit primitive ids (NULL to skip).
+ *   d_t   : optional DEVICE pointer, W*H float primary-hit distance (64 on a miss).
+ *   stream: hipStream_t (NULL = default stream).  The call is asynchronous
+ *           unless RT_RENDER_TIME is set or `stats` is non-NULL (stats are
+ *           read back, which synchronises the stream). */
+int rt_render_rows(rt_dscene* d, int row_begin, int row_end, uint8_t* d_rgb, int32_t* d_ids, float* d_t,
+                   void* stream, unsigned flags, rt_stats* stats);
+
+/* Row-interleaved partition for rendering one image on several GPUs.  The image is cut into bands of
+ * `band_rows` rows (a multiple of 16); rank r of nranks owns bands r, r+nranks, ...  rt_band_count
+ * returns how many bands that is.  rt_render_bands renders them PACKED: band k of this rank starts at row
+ * k*band_rows of d_rgb_local (W*band_rows*rt_band_count*3 bytes), ready for one gather of equal-sized
+ * tiles; rows past the bottom of the image are left untouched.  The reference has no multi-GPU path
+ * (it is listed as future work, doc/GPU Raytracing.pdf p.26); pixels are independent (camera.cu:91-94),
+ * which is what this partition relies on. */
+int rt_band_count(const rt_dscene* d, int band_rows, int rank, int nranks);
+int rt_render_bands(rt_dscene* d, int band_rows, int rank, int nranks, uint8_t* d_rgb_local, int32_t* d_ids_local,
+                    float* d_t_local, void* stream, unsigned flags, rt_stats* stats);
+
+/* Same as rt_render_rows, into HOST memory (adds the device->host copy of main.cu:56-57). */
+int rt_render_rows_host(rt_dscene* d, int row_begin, int row_end, uint8_t* h_rgb, int32_t* h_ids, float* h_t,
+                        unsigned flags, rt_stats* stats);
+
+/* 8-bit RGB PNG writer.  Replaces write_image (display/display.cpp:7-16). */
+int rt_write_png(const char* path, int width, int height, const uint8_t* rgb);
+
+const char* rt_strerror(int status);
+const char* rt_last_error(void);
+/* Library / kernel variant description, e.g. "rt_amd 0.1 gfx950". */
+const char* rt_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* RT_AMD_H */

@@ -1,0 +1,232 @@
+"""raytracer_amd -- host-side mirror of the render path's C ABI (include/rt_amd.h).
+
+The package is plumbing only: it loads ``librt_amd.so`` (HIP kernels for gfx950 + the C++ scene
+builder) with ctypes and exposes the same contract the reference exposes through its command line:
+a scene JSON + resources JSON + size + max depth go in, a top-left-origin RGB8 image comes out
+(reference: ``run -s scene.json [-w W -h H -m depth -r resources.json -i image.png]``,
+parsing/parsing.cu:145-175, main.cu:14-70).
+
+There is no CPU rendering path in here: without the HIP library, or without a GPU, rendering raises.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(_HERE)
+ASSETS = os.path.join(ROOT, "assets")
+LIB_PATH = os.path.join(_HERE, "librt_amd.so")
+
+RT_RENDER_COUNT_TESTS = 1
+RT_RENDER_TIME = 2
+
+# Every symbol include/rt_amd.h declares.
+ABI_SYMBOLS = (
+    "rt_scene_load", "rt_scene_destroy", "rt_scene_get_info", "rt_scene_dump_tree", "rt_scene_dump_triangles",
+    "rt_scene_dump_camera", "rt_scene_upload", "rt_dscene_destroy", "rt_render_rows", "rt_render_rows_host",
+    "rt_band_count", "rt_render_bands",
+    "rt_write_png", "rt_strerror", "rt_last_error", "rt_version",
+)
+
+
+class RtError(RuntimeError):
+    def __init__(self, status, detail):
+        super().__init__("rt_amd status %d: %s" % (status, detail))
+        self.status = status
+
+
+class SceneInfo(C.Structure):
+    _fields_ = [(n, C.c_int32) for n in (
+        "width", "height", "max_depth", "n_triangles", "n_spheres", "n_lights", "n_materials", "n_nodes", "n_leaves",
+        "n_empty_leaves", "n_leaf_refs", "tree_depth", "max_leaf_size", "has_bounce_materials", "shadows_enabled")]
+    _fields_ += [("_pad", C.c_int32), ("build_seconds", C.c_double), ("parse_seconds", C.c_double)]
+
+    def as_dict(self):
+        return {n: getattr(self, n) for n, _ in self._fields_ if n != "_pad"}
+
+
+class Stats(C.Structure):
+    _fields_ = [(n, C.c_uint64) for n in (
+        "rays", "shadow_rays", "node_tests", "leaf_visits", "tri_tests", "sphere_tests", "ub_leave_level0",
+        "ub_level_overflow", "ub_stack_overflow")] + [("kernel_ms", C.c_float)]
+
+    def as_dict(self):
+        return {n: getattr(self, n) for n, _ in self._fields_}
+
+
+_lib = None
+
+
+def lib():
+    """Load librt_amd.so; raise loudly when it has not been built (there is no fallback)."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise ImportError("%s is missing: run `make` (or __graft_entry__.build()) first; "
+                              "raytracer_amd has no non-HIP rendering path" % LIB_PATH)
+        L = C.CDLL(LIB_PATH)
+        L.rt_scene_load.argtypes = [C.c_char_p, C.c_char_p, C.c_char_p, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_void_p)]
+        L.rt_scene_destroy.argtypes = [C.c_void_p]
+        L.rt_scene_destroy.restype = None
+        L.rt_scene_get_info.argtypes = [C.c_void_p, C.POINTER(SceneInfo)]
+        L.rt_scene_dump_tree.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+        L.rt_scene_dump_triangles.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+        L.rt_scene_dump_camera.argtypes = [C.c_void_p, C.c_void_p]
+        L.rt_scene_upload.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_void_p)]
+        L.rt_dscene_destroy.argtypes = [C.c_void_p]
+        L.rt_dscene_destroy.restype = None
+        L.rt_render_rows.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                     C.c_uint, C.POINTER(Stats)]
+        L.rt_render_rows_host.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint,
+                                          C.POINTER(Stats)]
+        L.rt_band_count.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int]
+        L.rt_render_bands.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                      C.c_uint, C.POINTER(Stats)]
+        L.rt_write_png.argtypes = [C.c_char_p, C.c_int, C.c_int, C.c_void_p]
+        L.rt_strerror.argtypes = [C.c_int]
+        L.rt_strerror.restype = C.c_char_p
+        L.rt_last_error.restype = C.c_char_p
+        L.rt_version.restype = C.c_char_p
+        _lib = L
+    return _lib
+
+
+def _check(status):
+    if status != 0:
+        L = lib()
+        detail = L.rt_last_error().decode() or L.rt_strerror(status).decode()
+        raise RtError(status, detail)
+
+
+def version():
+    return lib().rt_version().decode()
+
+
+def asset(path):
+    """Resolve a path such as 'scenes/meshDragon.json' against the bundled assets directory."""
+    return path if os.path.isabs(path) else os.path.join(ASSETS, path)
+
+
+class Scene:
+    """Parsed scene with its octree, on the host (rt_scene)."""
+
+    def __init__(self, scene, width=512, height=512, max_depth=3, resources=None, base_dir=None):
+        self.h = C.c_void_p()
+        res = resources or os.path.join(ASSETS, "resources.json")
+        base = ASSETS if base_dir is None else base_dir
+        _check(lib().rt_scene_load(asset(scene).encode(), res.encode(), base.encode(), width, height, max_depth,
+                                   C.byref(self.h)))
+        self.width, self.height, self.max_depth = width, height, max_depth
+
+    def close(self):
+        if getattr(self, "h", None):
+            lib().rt_scene_destroy(self.h)
+            self.h = None
+
+    __del__ = close
+
+    def info(self):
+        i = SceneInfo()
+        _check(lib().rt_scene_get_info(self.h, C.byref(i)))
+        return i.as_dict()
+
+    def tree(self):
+        i = self.info()
+        kind = np.zeros(max(i["n_nodes"], 1), np.int32)
+        bounds = np.zeros((max(i["n_nodes"], 1), 6), np.float32)
+        refs = np.zeros(max(i["n_leaf_refs"], 1), np.int32)
+        _check(lib().rt_scene_dump_tree(self.h, kind.ctypes.data, bounds.ctypes.data, refs.ctypes.data))
+        return kind[:i["n_nodes"]], bounds[:i["n_nodes"]], refs[:i["n_leaf_refs"]]
+
+    def triangles(self):
+        n = self.info()["n_triangles"]
+        v = np.zeros((max(n, 1), 9), np.float32)
+        nn = np.zeros((max(n, 1), 9), np.float32)
+        m = np.zeros(max(n, 1), np.int32)
+        _check(lib().rt_scene_dump_triangles(self.h, v.ctypes.data, nn.ctypes.data, m.ctypes.data))
+        return v[:n], nn[:n], m[:n]
+
+    def camera(self):
+        out = np.zeros(19, np.float32)
+        _check(lib().rt_scene_dump_camera(self.h, out.ctypes.data))
+        return out
+
+
+class DeviceScene:
+    """A Scene resident in one GPU's HBM (rt_dscene)."""
+
+    def __init__(self, scene, device=0):
+        self.h = C.c_void_p()
+        self.scene = scene
+        self.device = device
+        self.width, self.height = scene.width, scene.height
+        _check(lib().rt_scene_upload(scene.h, device, C.byref(self.h)))
+
+    def close(self):
+        if getattr(self, "h", None):
+            lib().rt_dscene_destroy(self.h)
+            self.h = None
+
+    __del__ = close
+
+    def render_host(self, row_begin=0, row_end=None, want_ids=True, flags=0):
+        """Render rows into fresh numpy arrays (device->host copy included)."""
+        row_end = self.height if row_end is None else row_end
+        rgb = np.zeros((self.height, self.width, 3), np.uint8)
+        ids = np.full((self.height, self.width), -1, np.int32) if want_ids else None
+        ts = np.zeros((self.height, self.width), np.float32) if want_ids else None
+        st = Stats()
+        _check(lib().rt_render_rows_host(self.h, row_begin, row_end, rgb.ctypes.data,
+                                         ids.ctypes.data if want_ids else None,
+                                         ts.ctypes.data if want_ids else None, flags, C.byref(st)))
+        return rgb, ids, ts, st.as_dict()
+
+    def render_into(self, rgb_ptr, row_begin=0, row_end=None, ids_ptr=None, t_ptr=None, stream=None, flags=0,
+                    want_stats=False):
+        """Render rows into device buffers given as raw pointers (e.g. torch tensor .data_ptr())."""
+        row_end = self.height if row_end is None else row_end
+        st = Stats() if want_stats else None
+        _check(lib().rt_render_rows(self.h, row_begin, row_end, rgb_ptr, ids_ptr, t_ptr, stream, flags,
+                                    C.byref(st) if want_stats else None))
+        return st.as_dict() if want_stats else None
+
+
+    def band_count(self, band_rows, rank, nranks):
+        n = lib().rt_band_count(self.h, band_rows, rank, nranks)
+        if n < 0:
+            raise RtError(n, "rt_band_count: bad argument")
+        return n
+
+    def render_bands_into(self, rgb_ptr, band_rows, rank, nranks, ids_ptr=None, t_ptr=None, stream=None, flags=0,
+                          want_stats=False):
+        """Render this rank's row bands, packed, into a device buffer of band_count*band_rows rows."""
+        st = Stats() if want_stats else None
+        _check(lib().rt_render_bands(self.h, band_rows, rank, nranks, rgb_ptr, ids_ptr, t_ptr, stream, flags,
+                                     C.byref(st) if want_stats else None))
+        return st.as_dict() if want_stats else None
+
+
+def band_rows_of(height, band_rows, rank, nranks):
+    """Image rows owned by `rank` under the band partition, in packed order."""
+    rows = []
+    bands = (height + band_rows - 1) // band_rows
+    for b in range(rank, bands, nranks):
+        rows.extend(range(b * band_rows, min((b + 1) * band_rows, height)))
+    return rows
+
+
+def assemble_bands(tiles, height, band_rows):
+    """Full image from the per-rank packed band buffers of one gather (tiles[r] = rank r's buffer)."""
+    nranks = len(tiles)
+    out = np.zeros((height,) + tuple(tiles[0].shape[1:]), tiles[0].dtype)
+    for r, tile in enumerate(tiles):
+        rows = band_rows_of(height, band_rows, r, nranks)
+        out[rows] = np.asarray(tile)[:len(rows)]
+    return out
+
+
+def write_png(path, rgb):
+    rgb = np.ascontiguousarray(rgb, np.uint8)
+    h, w = rgb.shape[:2]
+    _check(lib().rt_write_png(path.encode(), w, h, rgb.ctypes.data))

@@ -1,0 +1,756 @@
+// rt_host.cpp -- host side of the render path: scene + resource parsing, OBJ ingest, mesh
+// transforms, octree construction straight into the flat HBM layout, PNG output.
+//
+// Everything here feeds the HIP kernels with bit-identical inputs to the ones the reference's
+// host code feeds its kernel, so the float arithmetic follows the reference operation by operation
+// (camera/camera.cu:45-74, mesh/mesh.cu:22-48, vertex/vertex.cu:8-12, triangle/triangle.cu:11-14,61-105,
+// vector/vector.cu:35-63, octtree/octtree.cu:14-20,90-112,162-174, parsing/parsing.cu:21-130,145-473).
+// Build with -ffp-contract=off.
+#include <algorithm>
+#include <chrono>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <map>
+#include <string>
+#include <vector>
+
+#include "rt_internal.h"
+
+// ------------------------------------------------------------------ errors
+static thread_local std::string g_last_error;
+void rt_set_error(const std::string& msg) { g_last_error = msg; }
+
+extern "C" const char* rt_last_error(void) { return g_last_error.c_str(); }
+extern "C" const char* rt_strerror(int status) {
+  switch (status) {
+    case RT_OK: return "ok";
+    case RT_ERR_ARG: return "invalid argument";
+    case RT_ERR_IO: return "file not found or unreadable";
+    case RT_ERR_PARSE: return "malformed scene, resource or mesh file";
+    case RT_ERR_LIMIT: return "scene exceeds a fixed limit of the render path";
+    case RT_ERR_DEVICE: return "HIP device error";
+    case RT_ERR_NOMEM: return "out of memory";
+    default: return "unknown status";
+  }
+}
+
+namespace {
+
+using Clock = std::chrono::steady_clock;
+inline double seconds_since(Clock::time_point t0) {
+  return std::chrono::duration<double>(Clock::now() - t0).count();
+}
+
+struct Fail {
+  int code; std::string msg;
+};
+
+bool slurp(const std::string& path, std::string& out) {
+  FILE* f = fopen(path.c_str(), "rb");
+  if (!f) return false;
+  fseek(f, 0, SEEK_END);
+  long n = ftell(f);
+  fseek(f, 0, SEEK_SET);
+  out.resize(n > 0 ? (size_t)n : 0);
+  size_t got = n > 0 ? fread(&out[0], 1, (size_t)n, f) : 0;
+  fclose(f);
+  out.resize(got);
+  return true;
+}
+
+// ----------------------------------------------------- host float helpers
+// Dot product with float products and a double accumulator (vector.cu:48-50).
+inline float dot_dacc(const float* a, const float* b) {
+  double s = 0.0;
+  s += (double)(a[0] * b[0]);
+  s += (double)(a[1] * b[1]);
+  s += (double)(a[2] * b[2]);
+  return (float)s;
+}
+inline void normalize_dacc(float* v) {   // vector.cu:57-63
+  const float m = sqrtf(dot_dacc(v, v));
+  v[0] = v[0] / m; v[1] = v[1] / m; v[2] = v[2] / m;
+}
+inline void cross3(float* r, const float* u, const float* v) {   // vector.cu:52-55
+  const float x = u[1] * v[2] - u[2] * v[1];
+  const float y = u[2] * v[0] - u[0] * v[2];
+  const float z = u[0] * v[1] - u[1] * v[0];
+  r[0] = x; r[1] = y; r[2] = z;
+}
+
+// ------------------------------------------------------------------- JSON
+// Small DOM; members keep file order and scalars keep their source text, because the reference
+// converts every number with stof/stoi of the literal (parsing.cu:207,215,230).
+struct Json {
+  enum Kind { SCALAR, OBJECT, ARRAY } kind = SCALAR;
+  std::string text;
+  std::vector<std::string> keys;   // OBJECT only
+  std::vector<Json> items;         // OBJECT values / ARRAY elements
+  float as_float() const { return strtof(text.c_str(), nullptr); }
+  int as_int() const { return atoi(text.c_str()); }
+  void floats(std::vector<float>& out) const { for (const Json& j : items) out.push_back(j.as_float()); }
+};
+
+class JsonReader {
+ public:
+  explicit JsonReader(const std::string& s) : s_(s) {}
+  Json parse() {
+    Json j = value();
+    skip();
+    if (pos_ != s_.size()) throw Fail{RT_ERR_PARSE, "trailing characters in JSON"};
+    return j;
+  }
+
+ private:
+  const std::string& s_;
+  size_t pos_ = 0;
+  void skip() { while (pos_ < s_.size() && isspace((unsigned char)s_[pos_])) pos_++; }
+  char peek() { skip(); if (pos_ >= s_.size()) throw Fail{RT_ERR_PARSE, "unexpected end of JSON"}; return s_[pos_]; }
+  void expect(char c) { if (peek() != c) throw Fail{RT_ERR_PARSE, std::string("JSON: expected '") + c + "'"}; pos_++; }
+  std::string quoted() {
+    expect('"');
+    std::string o;
+    while (pos_ < s_.size() && s_[pos_] != '"') {
+      char c = s_[pos_++];
+      if (c == '\\' && pos_ < s_.size()) {
+        char e = s_[pos_++];
+        switch (e) { case 'n': c = '\n'; break; case 't': c = '\t'; break; case 'r': c = '\r'; break; default: c = e; }
+      }
+      o.push_back(c);
+    }
+    if (pos_ >= s_.size()) throw Fail{RT_ERR_PARSE, "unterminated JSON string"};
+    pos_++;
+    return o;
+  }
+  Json value() {
+    Json j;
+    char c = peek();
+    if (c == '{') {
+      j.kind = Json::OBJECT; pos_++;
+      if (peek() == '}') { pos_++; return j; }
+      for (;;) {
+        j.keys.push_back(quoted());
+        expect(':');
+        j.items.push_back(value());
+        if (peek() == ',') { pos_++; continue; }
+        expect('}');
+        break;
+      }
+    } else if (c == '[') {
+      j.kind = Json::ARRAY; pos_++;
+      if (peek() == ']') { pos_++; return j; }
+      for (;;) {
+        j.items.push_back(value());
+        if (peek() == ',') { pos_++; continue; }
+        expect(']');
+        break;
+      }
+    } else if (c == '"') {
+      j.text = quoted();
+    } else {
+      size_t b = pos_;
+      while (pos_ < s_.size() && !isspace((unsigned char)s_[pos_]) && s_[pos_] != ',' && s_[pos_] != '}' && s_[pos_] != ']') pos_++;
+      if (pos_ == b) throw Fail{RT_ERR_PARSE, "JSON: empty value"};
+      j.text = s_.substr(b, pos_ - b);
+    }
+    return j;
+  }
+};
+
+Json read_json_file(const std::string& path) {
+  std::string src;
+  if (!slurp(path, src)) throw Fail{RT_ERR_IO, "cannot open " + path};
+  return JsonReader(src).parse();
+}
+
+// ------------------------------------------------------------------ meshes
+struct HostMesh {
+  std::vector<float> pos;        // 3 per OBJ position index
+  std::vector<float> nrm;        // 3 per position index (first normal seen in a face, or computed)
+  std::vector<uint8_t> used;     // position index referenced by a face
+  std::vector<int32_t> face;     // 3 position indices per face
+  std::vector<float> face_n;     // 3 per face
+  std::vector<int32_t> adj_start, adj;   // CSR vertex -> faces, in face order, one entry per corner
+  bool file_normals = false;
+  size_t n_faces() const { return face.size() / 3; }
+};
+
+// Cursor over one line that splits on a single delimiter character the way std::getline(stream,
+// token, delim) does (parsing.cu:35-118 tokenises every line like that).
+struct Splitter {
+  const char* p; const char* end; bool exhausted;
+  Splitter(const char* b, const char* e) : p(b), end(e), exhausted(b == e) {}
+  // Returns [tb,te) of the next token; empty + exhausted once the line is consumed.
+  void next(char delim, const char*& tb, const char*& te) {
+    if (exhausted || p >= end) { exhausted = true; tb = te = end; return; }
+    tb = p;
+    const char* q = (const char*)memchr(p, delim, (size_t)(end - p));
+    if (q) { te = q; p = q + 1; } else { te = end; p = end; }
+  }
+};
+inline float tok_float(Splitter& sp) {
+  const char *b, *e; sp.next(' ', b, e);
+  char buf[64]; size_t n = std::min<size_t>((size_t)(e - b), sizeof(buf) - 1);
+  memcpy(buf, b, n); buf[n] = 0;
+  return strtof(buf, nullptr);
+}
+inline long tok_index(Splitter& sp, char delim) {
+  const char *b, *e; sp.next(delim, b, e);
+  char buf[32]; size_t n = std::min<size_t>((size_t)(e - b), sizeof(buf) - 1);
+  memcpy(buf, b, n); buf[n] = 0;
+  return (long)strtoul(buf, nullptr, 10);
+}
+
+void compute_face_normal(HostMesh& m, size_t f) {   // triangle.cu:11-14
+  const float* p0 = &m.pos[3 * m.face[3 * f + 0]];
+  const float* p1 = &m.pos[3 * m.face[3 * f + 1]];
+  const float* p2 = &m.pos[3 * m.face[3 * f + 2]];
+  const float a[3] = {p1[0] - p0[0], p1[1] - p0[1], p1[2] - p0[2]};
+  const float b[3] = {p2[0] - p0[0], p2[1] - p0[1], p2[2] - p0[2]};
+  float n[3]; cross3(n, a, b); normalize_dacc(n);
+  m.face_n[3 * f + 0] = n[0]; m.face_n[3 * f + 1] = n[1]; m.face_n[3 * f + 2] = n[2];
+}
+void compute_vertex_normals(HostMesh& m) {          // vertex.cu:8-12 for every used vertex
+  const size_t nv = m.used.size();
+  for (size_t v = 0; v < nv; v++) {
+    if (!m.used[v]) continue;
+    float n[3] = {0.f, 0.f, 0.f};
+    for (int32_t k = m.adj_start[v]; k < m.adj_start[v + 1]; k++) {
+      const float* fn = &m.face_n[3 * m.adj[k]];
+      n[0] = n[0] + fn[0]; n[1] = n[1] + fn[1]; n[2] = n[2] + fn[2];
+    }
+    normalize_dacc(n);
+    m.nrm[3 * v + 0] = n[0]; m.nrm[3 * v + 1] = n[1]; m.nrm[3 * v + 2] = n[2];
+  }
+}
+
+// OBJ subset of parsing.cu:21-130: skip to the first "v" line; one contiguous block each of v, vt, vn
+// (in that order, vt/vn optional); skip to the first "f"; triangles until the first non-"f" line.
+HostMesh load_obj(const std::string& path) {
+  std::string src;
+  if (!slurp(path, src)) throw Fail{RT_ERR_IO, "No " + path + " has been found"};
+  HostMesh m;
+  const char* cur = src.data();
+  const char* const fin = src.data() + src.size();
+  const char *lb = nullptr, *le = nullptr;
+  bool eof = false;
+  auto fetch = [&]() {   // next line without its '\n'; past the end every line is empty
+    if (cur >= fin) { lb = le = fin; eof = true; return; }
+    lb = cur;
+    const char* q = (const char*)memchr(cur, '\n', (size_t)(fin - cur));
+    if (q) { le = q; cur = q + 1; } else { le = fin; cur = fin; }
+  };
+  auto head_is = [&](Splitter& sp, const char* word) {
+    const char *b, *e; sp.next(' ', b, e);
+    size_t n = strlen(word);
+    return (size_t)(e - b) == n && memcmp(b, word, n) == 0;
+  };
+  std::vector<float> vn; size_t n_vt = 0;
+  // skip to the first vertex
+  for (;;) {
+    fetch();
+    if (eof) throw Fail{RT_ERR_PARSE, "no vertex lines in " + path};
+    Splitter sp(lb, le);
+    if (head_is(sp, "v")) { for (int k = 0; k < 3; k++) m.pos.push_back(tok_float(sp)); break; }
+  }
+  enum { V, VT, VN, SEEK_F, F, DONE } state = V;
+  std::vector<int32_t> first_normal;   // per position index, -1 = none
+  while (state != DONE) {
+    fetch();
+    Splitter sp(lb, le);
+    const char *hb, *he; sp.next(' ', hb, he);
+    auto is = [&](const char* w) { size_t n = strlen(w); return (size_t)(he - hb) == n && memcmp(hb, w, n) == 0; };
+    if (state == V) { if (is("v")) { for (int k = 0; k < 3; k++) m.pos.push_back(tok_float(sp)); continue; } state = VT; }
+    if (state == VT) { if (is("vt")) { tok_float(sp); tok_float(sp); n_vt++; continue; } state = VN; }
+    if (state == VN) { if (is("vn")) { for (int k = 0; k < 3; k++) vn.push_back(tok_float(sp)); continue; } state = SEEK_F; }
+    if (state == SEEK_F) {
+      if (!is("f")) { if (eof) throw Fail{RT_ERR_PARSE, "no face lines in " + path}; continue; }
+      state = F;
+      const size_t nv = m.pos.size() / 3;
+      m.used.assign(nv, 0); m.nrm.assign(3 * nv, 0.f); first_normal.assign(nv, -1);
+      m.file_normals = !vn.empty();
+    }
+    if (state == F) {
+      if (!is("f")) { state = DONE; break; }
+      const size_t nv = m.used.size();
+      for (int c = 0; c < 3; c++) {
+        long vin, nin = -1;
+        if (m.file_normals) vin = tok_index(sp, '/') - 1; else vin = tok_index(sp, ' ') - 1;
+        if (n_vt) (void)tok_index(sp, '/');
+        else if (m.file_normals) { const char *b, *e; sp.next('/', b, e); }
+        if (m.file_normals) nin = tok_index(sp, ' ') - 1;
+        if (vin < 0 || (size_t)vin >= nv) throw Fail{RT_ERR_PARSE, "face references a missing vertex in " + path};
+        if (!m.used[vin]) {
+          m.used[vin] = 1;
+          if (nin != -1) {
+            if (nin < 0 || (size_t)nin >= vn.size() / 3) throw Fail{RT_ERR_PARSE, "face references a missing normal in " + path};
+            m.nrm[3 * vin + 0] = vn[3 * nin + 0]; m.nrm[3 * vin + 1] = vn[3 * nin + 1]; m.nrm[3 * vin + 2] = vn[3 * nin + 2];
+          }
+        }
+        m.face.push_back((int32_t)vin);
+      }
+    }
+  }
+  const size_t nf = m.n_faces(), nv = m.used.size();
+  // adjacency (Vertex::addT order = face order, one entry per corner)
+  m.adj_start.assign(nv + 1, 0);
+  for (int32_t v : m.face) m.adj_start[v + 1]++;
+  for (size_t v = 0; v < nv; v++) m.adj_start[v + 1] += m.adj_start[v];
+  m.adj.resize(m.face.size());
+  { std::vector<int32_t> fill(m.adj_start.begin(), m.adj_start.end() - 1);
+    for (size_t f = 0; f < nf; f++) for (int c = 0; c < 3; c++) m.adj[fill[m.face[3 * f + c]]++] = (int32_t)f; }
+  m.face_n.resize(3 * nf);
+  for (size_t f = 0; f < nf; f++) compute_face_normal(m, f);   // Triangle ctor (triangle.cu:9)
+  if (!m.file_normals) compute_vertex_normals(m);              // parsing.cu:121
+  return m;
+}
+
+void mesh_scale(HostMesh& m, const std::vector<float>& s) {       // mesh.cu:22-26
+  for (size_t v = 0; v < m.used.size(); v++) for (int k = 0; k < 3; k++) m.pos[3 * v + k] = m.pos[3 * v + k] * s[k];
+}
+void mesh_translate(HostMesh& m, const std::vector<float>& t) {   // mesh.cu:44-48
+  for (size_t v = 0; v < m.used.size(); v++) for (int k = 0; k < 3; k++) m.pos[3 * v + k] = m.pos[3 * v + k] + t[k];
+}
+void mesh_rotate(HostMesh& m, const std::vector<float>& r) {      // mesh.cu:28-42, vector.cu:35-41
+  const float ang[3] = {(float)(M_PI * r[0] / 180), (float)(M_PI * r[1] / 180), (float)(M_PI * r[2] / 180)};
+  for (int axis = 0; axis < 3; axis++) {
+    const float c = cosf(ang[axis]), s = sinf(ang[axis]);
+    float R[3][3];
+    if (axis == 0) { float t[3][3] = {{1, 0, 0}, {0, c, -s}, {0, s, c}}; memcpy(R, t, sizeof R); }
+    else if (axis == 1) { float t[3][3] = {{c, 0, s}, {0, 1, 0}, {-s, 0, c}}; memcpy(R, t, sizeof R); }
+    else { float t[3][3] = {{c, -s, 0}, {s, c, 0}, {0, 0, 1}}; memcpy(R, t, sizeof R); }
+    for (size_t v = 0; v < m.used.size(); v++) {
+      float* p = &m.pos[3 * v];
+      float o[3];
+      for (int i = 0; i < 3; i++) o[i] = R[i][0] * p[0] + R[i][1] * p[1] + R[i][2] * p[2];
+      p[0] = o[0]; p[1] = o[1]; p[2] = o[2];
+    }
+  }
+  for (size_t f = 0; f < m.n_faces(); f++) compute_face_normal(m, f);
+  compute_vertex_normals(m);
+}
+
+// ------------------------------------------------------------------ octree
+// Separating-axis test of triangle.cu:61-105: nine edge x box-normal axes only, projections with
+// the double-accumulating dot, intervals seeded with +-64.
+bool triangle_touches_box(const float* tv, const float* ini, const float* end) {
+  const float* v0 = tv; const float* v1 = tv + 3; const float* v2 = tv + 6;
+  const float edge[3][3] = {{v1[0] - v0[0], v1[1] - v0[1], v1[2] - v0[2]},
+                            {v2[0] - v1[0], v2[1] - v1[1], v2[2] - v1[2]},
+                            {v0[0] - v2[0], v0[1] - v2[1], v0[2] - v2[2]}};
+  static const float unit[3][3] = {{1, 0, 0}, {0, 1, 0}, {0, 0, 1}};
+  const float corner[8][3] = {{ini[0], ini[1], ini[2]}, {end[0], ini[1], ini[2]}, {ini[0], end[1], ini[2]},
+                              {ini[0], ini[1], end[2]}, {end[0], end[1], ini[2]}, {end[0], ini[1], end[2]},
+                              {ini[0], end[1], end[2]}, {end[0], end[1], end[2]}};
+  for (int bi = 0; bi < 3; bi++) {
+    for (int ei = 0; ei < 3; ei++) {
+      float ax[3]; cross3(ax, edge[ei], unit[bi]);
+      if (!dot_dacc(ax, ax)) continue;
+      float tmin = RT_INF, tmax = -RT_INF, bmin = RT_INF, bmax = -RT_INF;
+      for (int j = 0; j < 3; j++) {
+        const float pr = dot_dacc(tv + 3 * j, ax);
+        tmax = std::max(tmax, pr); tmin = std::min(tmin, pr);
+      }
+      for (int c = 0; c < 8; c++) {
+        const float pr = dot_dacc(corner[c], ax);
+        bmax = std::max(bmax, pr); bmin = std::min(bmin, pr);
+      }
+      if (tmax < bmin || tmin > bmax) return false;
+    }
+  }
+  return true;
+}
+
+// Top-down construction that yields the tree the reference's incremental insertion yields
+// (octtree.cu:14-20,162-174): a node's triangle set is the parent's set filtered by the node's box
+// test, kept in ascending triangle order (= insertion order), and a node is a branch exactly when
+// that set has more than 50 members, because a leaf splits the moment its 51st member arrives and
+// re-inserts its members in order.  Nodes are laid out so the eight children of a branch are
+// consecutive and subtrees follow depth-first order, which is the order rays walk them.
+struct TreeBuilder {
+  rt_scene& sc;
+  int max_depth = 0;
+  explicit TreeBuilder(rt_scene& s) : sc(s) {}
+
+  static void child_box(const float* ini, const float* end, int c, float* ci, float* ce) {   // octtree.cu:95-111
+    for (int k = 0; k < 3; k++) {
+      const float mid = (end[k] + ini[k]) / 2;
+      const bool high = (c >> k) & 1;
+      ci[k] = high ? mid : ini[k];
+      ce[k] = high ? end[k] : mid;
+    }
+  }
+  static void set_bounds(RtNode& n, const float* ini, const float* end) {
+    for (int k = 0; k < 3; k++) { n.a[k] = ini[k]; n.b[k] = end[k]; }
+  }
+  static void set_links(RtNode& n, int32_t first, int32_t count) {
+    memcpy(&n.a[3], &first, 4); memcpy(&n.b[3], &count, 4);
+  }
+
+  // Node `id` (bounds already set) receives `tris`; depth of the root is 0.
+  void fill(int32_t id, const std::vector<int32_t>& tris, int depth, bool force_branch) {
+    if (depth > max_depth) max_depth = depth;
+    if (!force_branch && (int)tris.size() <= RT_LEAF_CAP) {
+      set_links(sc.nodes[id], (int32_t)sc.leaf_refs.size(), (int32_t)tris.size());
+      sc.leaf_refs.insert(sc.leaf_refs.end(), tris.begin(), tris.end());
+      return;
+    }
+    if (depth + 1 >= RT_OCT_STACK)
+      throw Fail{RT_ERR_LIMIT, "octree would be deeper than the 20-entry traversal stack (more than 50 triangles meet in one point)"};
+    const int32_t first = (int32_t)sc.nodes.size();
+    set_links(sc.nodes[id], first, -1);
+    float ini[3], end[3];
+    for (int k = 0; k < 3; k++) { ini[k] = sc.nodes[id].a[k]; end[k] = sc.nodes[id].b[k]; }
+    sc.nodes.resize(sc.nodes.size() + 8);
+    for (int c = 0; c < 8; c++) {
+      float ci[3], ce[3]; child_box(ini, end, c, ci, ce);
+      set_bounds(sc.nodes[first + c], ci, ce);
+    }
+    std::vector<int32_t> sub;
+    for (int c = 0; c < 8; c++) {
+      float ci[3], ce[3];
+      for (int k = 0; k < 3; k++) { ci[k] = sc.nodes[first + c].a[k]; ce[k] = sc.nodes[first + c].b[k]; }
+      sub.clear();
+      for (int32_t t : tris) if (triangle_touches_box(&sc.tri_verts[9 * (size_t)t], ci, ce)) sub.push_back(t);
+      fill(first + c, sub, depth + 1, false);
+    }
+  }
+
+  void build() {   // main.cu:25-31
+    const float ini[3] = {-RT_INF / 4, -RT_INF / 4, RT_INF / 4}, end[3] = {RT_INF / 4, RT_INF / 4, -RT_INF / 4};
+    sc.nodes.clear(); sc.leaf_refs.clear();
+    sc.nodes.resize(1);
+    set_bounds(sc.nodes[0], ini, end);
+    std::vector<int32_t> all;
+    const int32_t nt = (int32_t)(sc.tri_verts.size() / 9);
+    for (int32_t t = 0; t < nt; t++) if (triangle_touches_box(&sc.tri_verts[9 * (size_t)t], ini, end)) all.push_back(t);
+    fill(0, all, 0, true);
+  }
+};
+
+void tree_summary(const rt_scene& sc, int32_t id, int depth, rt_scene_info& o) {
+  int32_t first, count;
+  memcpy(&first, &sc.nodes[id].a[3], 4); memcpy(&count, &sc.nodes[id].b[3], 4);
+  if (depth > o.tree_depth) o.tree_depth = depth;
+  if (count < 0) { for (int c = 0; c < 8; c++) tree_summary(sc, first + c, depth + 1, o); return; }
+  o.n_leaves++; o.n_leaf_refs += count;
+  if (!count) o.n_empty_leaves++;
+  if (count > o.max_leaf_size) o.max_leaf_size = count;
+}
+
+// -------------------------------------------------------------- scene load
+struct MaterialTable {
+  std::vector<RtMaterial> mats;
+  std::map<std::string, int> by_name;
+};
+
+MaterialTable load_resources(const std::string& path) {   // parsing.cu:177-269
+  MaterialTable T;
+  const Json root = read_json_file(path);
+  for (size_t i = 0; i < root.keys.size(); i++) {
+    if (root.keys[i] != "materials") continue;
+    for (const Json& entry : root.items[i].items) {
+      std::string type, name; std::vector<float> col, att; int shininess = 0; float ior = 0.f;
+      for (size_t k = 0; k < entry.keys.size(); k++) {
+        const std::string& key = entry.keys[k]; const Json& val = entry.items[k];
+        if (key == "__type__" || key == "brdf") type = val.text;
+        else if (key == "name") name = val.text;
+        else if (key == "color") val.floats(col);
+        else if (key == "attenuation") val.floats(att);
+        else if (key == "refraction_index") ior = val.as_float();
+        else if (key == "brdfParams") {
+          for (size_t q = 0; q < val.keys.size(); q++) if (val.keys[q] == "shininess") shininess = val.items[q].as_int();
+        }
+      }
+      RtMaterial m; memset(&m, 0, sizeof m);
+      if (type == "lambert") m.type = RT_LAMBERT;
+      else if (type == "blinnPhong") { m.type = RT_PHONG; m.param = (float)shininess; }
+      else if (type == "reflective_material") m.type = RT_REFLECTIVE;
+      else if (type == "dielectric_material") { m.type = RT_DIELECTRIC; m.param = ior; }
+      else continue;
+      // Entries without a colour (the texture-flavoured ones) cannot be evaluated: the reference
+      // reads past the end of an empty vector for them.  They stay unknown to scenes.
+      if (col.size() < 3) continue;
+      if (m.type == RT_DIELECTRIC && att.size() < 3) continue;
+      for (int c = 0; c < 3; c++) { m.col[c] = col[c]; if (m.type == RT_DIELECTRIC) m.att[c] = att[c]; }
+      T.by_name[name] = (int)T.mats.size();
+      T.mats.push_back(m);
+    }
+  }
+  return T;
+}
+
+void load_scene_into(rt_scene& sc, const std::string& scene_path, const std::string& res_path,
+                     const std::string& base_dir, int W, int H, int depth) {
+  const auto t_parse = Clock::now();
+  MaterialTable T = load_resources(res_path);
+  sc.materials = T.mats;
+  const Json world = read_json_file(scene_path);
+
+  std::vector<float> eye, up, target; float fov = 0.f; bool have_camera = false;
+  float bg[3] = {0.f, 0.f, 0.f}, scene_refr = 1.0f; bool shadows = true;   // parsing.cu:16-18
+  std::vector<std::vector<int32_t>> mesh_mats;
+  std::vector<std::vector<int32_t>> sphere_mats;
+
+  for (size_t i = 0; i < world.keys.size(); i++) {   // parsing.cu:275-470, keys in file order
+    const std::string& key = world.keys[i]; const Json& val = world.items[i];
+    if (key == "camera") {
+      for (size_t k = 0; k < val.keys.size(); k++) {
+        const std::string& ck = val.keys[k]; const Json& cv = val.items[k];
+        if (ck == "fov") fov = (float)(M_PI * cv.as_float() / 180);
+        else if (ck == "position") cv.floats(eye);
+        else if (ck == "up") cv.floats(up);
+        else if (ck == "target") cv.floats(target);
+      }
+      have_camera = true;
+    } else if (key == "objects") {
+      for (const Json& obj : val.items) {
+        std::string type, file; std::vector<float> pos, sca, rot, trans; float radius = 0.f; std::vector<int32_t> mats;
+        for (size_t k = 0; k < obj.keys.size(); k++) {
+          const std::string& ok = obj.keys[k]; const Json& ov = obj.items[k];
+          if (ok == "__type__") type = ov.text;
+          else if (ok == "file_path") file = ov.text;
+          else if (ok == "scaling") ov.floats(sca);
+          else if (ok == "rotation") ov.floats(rot);
+          else if (ok == "translation") ov.floats(trans);
+          else if (ok == "radius") radius = ov.as_float();
+          else if (ok == "position") ov.floats(pos);
+          else if (ok == "materials") {
+            for (const Json& mn : ov.items) {
+              auto it = T.by_name.find(mn.text);
+              if (it == T.by_name.end()) throw Fail{RT_ERR_PARSE, "unknown material '" + mn.text + "' in " + scene_path};
+              mats.push_back(it->second);
+            }
+          }
+        }
+        if (type == "sphere") {
+          if (pos.size() < 3) throw Fail{RT_ERR_PARSE, "sphere without a position in " + scene_path};
+          RtSphere s; memset(&s, 0, sizeof s);
+          s.c[0] = pos[0]; s.c[1] = pos[1]; s.c[2] = pos[2]; s.r = radius;
+          sc.spheres.push_back(s); sphere_mats.push_back(mats);
+        } else if (type == "mesh") {
+          const std::string path = (!file.empty() && file[0] == '/') ? file : base_dir + file;
+          HostMesh m = load_obj(path);
+          if ((sca.size() && sca.size() < 3) || (rot.size() && rot.size() < 3) || (trans.size() && trans.size() < 3))
+            throw Fail{RT_ERR_PARSE, "mesh transform needs three components in " + scene_path};
+          if (sca.size()) mesh_scale(m, sca);        // parsing.cu:380-382: always scale, rotate, translate
+          if (rot.size()) mesh_rotate(m, rot);
+          if (trans.size()) mesh_translate(m, trans);
+          const int32_t mesh_id = (int32_t)mesh_mats.size();
+          mesh_mats.push_back(mats);
+          for (size_t f = 0; f < m.n_faces(); f++) {   // mesh.cu:65-97
+            RtTriGeom g; RtTriShade s; memset(&g, 0, sizeof g); memset(&s, 0, sizeof s);
+            const float* p[3]; const float* n[3];
+            for (int c = 0; c < 3; c++) { p[c] = &m.pos[3 * m.face[3 * f + c]]; n[c] = &m.nrm[3 * m.face[3 * f + c]]; }
+            for (int k = 0; k < 3; k++) {
+              g.v0[k] = p[0][k]; g.e1[k] = p[1][k] - p[0][k]; g.e2[k] = p[2][k] - p[0][k];
+              s.v1[k] = p[1][k]; s.v2[k] = p[2][k]; s.n0[k] = n[0][k]; s.n1[k] = n[1][k]; s.n2[k] = n[2][k];
+            }
+            g.mesh = mesh_id;
+            sc.tri_geom.push_back(g); sc.tri_shade.push_back(s);
+            for (int c = 0; c < 3; c++) for (int k = 0; k < 3; k++) { sc.tri_verts.push_back(p[c][k]); sc.tri_normals.push_back(n[c][k]); }
+          }
+        }
+      }
+    } else if (key == "lights") {
+      for (const Json& li : val.items) {
+        std::string type; std::vector<float> pos, col, dir; float angle_deg = 0.f;
+        for (size_t k = 0; k < li.keys.size(); k++) {
+          const std::string& lk = li.keys[k]; const Json& lv = li.items[k];
+          if (lk == "__type__") type = lv.text;
+          else if (lk == "position") lv.floats(pos);
+          else if (lk == "color") lv.floats(col);
+          else if (lk == "direction") lv.floats(dir);
+          else if (lk == "angle") angle_deg = lv.as_float();
+        }
+        RtLight L; memset(&L, 0, sizeof L);
+        const bool spot = type == "spot_light", point = type == "point_light", dirl = type == "directional_light",
+                   amb = type == "ambient_light";
+        if (!(spot || point || dirl || amb)) continue;
+        if (col.size() < 3 || ((spot || point) && pos.size() < 3) || ((spot || dirl) && dir.size() < 3))
+          throw Fail{RT_ERR_PARSE, "light is missing a field in " + scene_path};
+        for (int c = 0; c < 3; c++) L.col[c] = col[c];
+        if (spot || point) for (int c = 0; c < 3; c++) L.pos[c] = pos[c];
+        if (spot || dirl) {
+          float d[3] = {dir[0], dir[1], dir[2]};
+          normalize_dacc(d);               // parsing.cu:427,437
+          if (dirl) normalize_dacc(d);     // DirectionalLight's constructor normalises once more (lights.cu:25-27)
+          for (int c = 0; c < 3; c++) L.dir[c] = d[c];
+        }
+        if (spot) { L.type = RT_SPOT; L.angle = (float)(M_PI * angle_deg / 180); L.cos_half = cosf(L.angle / 2); }
+        else if (point) L.type = RT_PUNCTUAL;
+        else if (dirl) L.type = RT_DIRECTIONAL;
+        else L.type = RT_AMBIENT;
+        sc.lights.push_back(L);
+      }
+    } else if (key == "params") {
+      for (size_t k = 0; k < val.keys.size(); k++) {
+        const std::string& pk = val.keys[k]; const Json& pv = val.items[k];
+        if (pk == "background_color") { int c = 0; for (const Json& x : pv.items) if (c < 3) bg[c++] = x.as_float(); }
+        else if (pk == "enable_shadows") shadows = (pv.text == "true");
+        else if (pk == "refraction_index") scene_refr = pv.as_float();
+      }
+    }
+  }
+  if (!have_camera || eye.size() < 3 || up.size() < 3 || target.size() < 3)
+    throw Fail{RT_ERR_PARSE, "scene has no usable camera: " + scene_path};
+
+  // material lists: spheres first, then meshes
+  for (size_t s = 0; s < sc.spheres.size(); s++) {
+    sc.spheres[s].mat_first = (int32_t)sc.mat_index.size(); sc.spheres[s].mat_count = (int32_t)sphere_mats[s].size();
+    sc.mat_index.insert(sc.mat_index.end(), sphere_mats[s].begin(), sphere_mats[s].end());
+  }
+  for (auto& mm : mesh_mats) {
+    sc.mesh_mat_first.push_back((int32_t)sc.mat_index.size()); sc.mesh_mat_count.push_back((int32_t)mm.size());
+    sc.mat_index.insert(sc.mat_index.end(), mm.begin(), mm.end());
+  }
+
+  // camera basis and frustum (camera.cu:50-68)
+  RtCamera& c = sc.cam; memset(&c, 0, sizeof c);
+  float w[3] = {eye[0] - target[0], eye[1] - target[1], eye[2] - target[2]}; normalize_dacc(w);
+  const float upv[3] = {up[0], up[1], up[2]};
+  float u[3]; cross3(u, upv, w); normalize_dacc(u);
+  float v[3]; cross3(v, w, u);
+  const float top = RT_NEAR * tanf(fov / 2);
+  const float right = (float)(unsigned short)W * top / (float)(unsigned short)H;
+  for (int k = 0; k < 3; k++) { c.u[k] = u[k]; c.v[k] = v[k]; c.w[k] = w[k]; c.pos[k] = eye[k]; c.bg[k] = bg[k]; }
+  c.top = top; c.bottom = -top; c.right = right; c.left = -right;
+  c.scene_refr = scene_refr; c.width = W; c.height = H; c.max_depth = depth; c.shadows = shadows ? 1 : 0;
+
+  rt_scene_info& I = sc.info; memset(&I, 0, sizeof I);
+  I.parse_seconds = seconds_since(t_parse);
+  const auto t_build = Clock::now();
+  if (!mesh_mats.empty()) { TreeBuilder tb(sc); tb.build(); }
+  I.build_seconds = seconds_since(t_build);
+  I.width = W; I.height = H; I.max_depth = depth;
+  I.n_triangles = (int32_t)sc.tri_geom.size(); I.n_spheres = (int32_t)sc.spheres.size();
+  I.n_lights = (int32_t)sc.lights.size(); I.n_materials = (int32_t)sc.materials.size();
+  I.n_nodes = (int32_t)sc.nodes.size(); I.shadows_enabled = c.shadows;
+  if (!sc.nodes.empty()) tree_summary(sc, 0, 0, I);
+  for (int32_t mi : sc.mat_index) if (sc.materials[mi].type == RT_REFLECTIVE || sc.materials[mi].type == RT_DIELECTRIC) I.has_bounce_materials = 1;
+}
+
+void dump_tree_rec(const rt_scene& sc, int32_t id, int32_t* kind, float* bounds, int32_t* refs, size_t& ni, size_t& ri) {
+  int32_t first, count;
+  memcpy(&first, &sc.nodes[id].a[3], 4); memcpy(&count, &sc.nodes[id].b[3], 4);
+  for (int k = 0; k < 3; k++) { bounds[6 * ni + k] = sc.nodes[id].a[k]; bounds[6 * ni + 3 + k] = sc.nodes[id].b[k]; }
+  kind[ni++] = count;
+  if (count < 0) { for (int c = 0; c < 8; c++) dump_tree_rec(sc, first + c, kind, bounds, refs, ni, ri); }
+  else for (int32_t k = 0; k < count; k++) refs[ri++] = sc.leaf_refs[first + k];
+}
+
+// ---------------------------------------------------------------------- PNG
+uint32_t crc_table[256]; bool crc_ready = false;
+uint32_t crc32_update(uint32_t c, const uint8_t* p, size_t n) {
+  if (!crc_ready) {
+    for (uint32_t i = 0; i < 256; i++) { uint32_t k = i; for (int b = 0; b < 8; b++) k = (k & 1) ? 0xEDB88320u ^ (k >> 1) : k >> 1; crc_table[i] = k; }
+    crc_ready = true;
+  }
+  for (size_t i = 0; i < n; i++) c = crc_table[(c ^ p[i]) & 0xFF] ^ (c >> 8);
+  return c;
+}
+void put_be32(std::vector<uint8_t>& v, uint32_t x) { v.push_back(x >> 24); v.push_back(x >> 16); v.push_back(x >> 8); v.push_back(x); }
+void png_chunk(std::vector<uint8_t>& out, const char* tag, const std::vector<uint8_t>& body) {
+  put_be32(out, (uint32_t)body.size());
+  const size_t start = out.size();
+  out.insert(out.end(), tag, tag + 4);
+  out.insert(out.end(), body.begin(), body.end());
+  put_be32(out, crc32_update(0xFFFFFFFFu, &out[start], out.size() - start) ^ 0xFFFFFFFFu);
+}
+
+}  // namespace
+
+// ==================================================================== C ABI
+extern "C" int rt_scene_load(const char* scene_json, const char* resources_json, const char* base_dir,
+                             int width, int height, int max_depth, rt_scene** out) {
+  if (!scene_json || !resources_json || !out) { rt_set_error("rt_scene_load: NULL argument"); return RT_ERR_ARG; }
+  *out = nullptr;
+  if (width < 1 || height < 1 || width > 65535 || height > 65535) { rt_set_error("image size must be 1..65535 per side"); return RT_ERR_ARG; }
+  // The ray stack holds 10 rays (ray.cuh:15-18); the reference is only safe up to depth 9.
+  if (max_depth < 0 || max_depth >= RT_RAY_STACK) { rt_set_error("max ray depth must be 0..9"); return RT_ERR_LIMIT; }
+  std::string bd = base_dir ? base_dir : "";
+  if (!bd.empty() && bd.back() != '/') bd.push_back('/');
+  rt_scene* sc = nullptr;
+  try {
+    sc = new rt_scene();
+    load_scene_into(*sc, scene_json, resources_json, bd, width, height, max_depth);
+  } catch (const Fail& f) {
+    delete sc; rt_set_error(f.msg); return f.code;
+  } catch (const std::bad_alloc&) {
+    delete sc; rt_set_error("out of host memory"); return RT_ERR_NOMEM;
+  } catch (const std::exception& e) {
+    delete sc; rt_set_error(e.what()); return RT_ERR_PARSE;
+  }
+  *out = sc;
+  return RT_OK;
+}
+
+extern "C" void rt_scene_destroy(rt_scene* s) { delete s; }
+
+extern "C" int rt_scene_get_info(const rt_scene* s, rt_scene_info* out) {
+  if (!s || !out) { rt_set_error("rt_scene_get_info: NULL argument"); return RT_ERR_ARG; }
+  *out = s->info;
+  return RT_OK;
+}
+
+extern "C" int rt_scene_dump_tree(const rt_scene* s, int32_t* kind, float* bounds, int32_t* refs) {
+  if (!s || !kind || !bounds || !refs) { rt_set_error("rt_scene_dump_tree: NULL argument"); return RT_ERR_ARG; }
+  if (s->nodes.empty()) return RT_OK;
+  size_t ni = 0, ri = 0;
+  dump_tree_rec(*s, 0, kind, bounds, refs, ni, ri);
+  return RT_OK;
+}
+
+extern "C" int rt_scene_dump_triangles(const rt_scene* s, float* verts, float* normals, int32_t* mesh) {
+  if (!s || !verts || !normals || !mesh) { rt_set_error("rt_scene_dump_triangles: NULL argument"); return RT_ERR_ARG; }
+  if (!s->tri_verts.empty()) {
+    memcpy(verts, s->tri_verts.data(), s->tri_verts.size() * 4);
+    memcpy(normals, s->tri_normals.data(), s->tri_normals.size() * 4);
+  }
+  for (size_t i = 0; i < s->tri_geom.size(); i++) mesh[i] = s->tri_geom[i].mesh;
+  return RT_OK;
+}
+
+extern "C" int rt_scene_dump_camera(const rt_scene* s, float* o) {
+  if (!s || !o) { rt_set_error("rt_scene_dump_camera: NULL argument"); return RT_ERR_ARG; }
+  const RtCamera& c = s->cam;
+  memcpy(o, c.u, 12); memcpy(o + 3, c.v, 12); memcpy(o + 6, c.w, 12); memcpy(o + 9, c.pos, 12);
+  o[12] = c.left; o[13] = c.right; o[14] = c.bottom; o[15] = c.top; memcpy(o + 16, c.bg, 12);
+  return RT_OK;
+}
+
+// 8-bit RGB, filter 0 on every row, zlib stream of stored deflate blocks (no compression library needed).
+extern "C" int rt_write_png(const char* path, int width, int height, const uint8_t* rgb) {
+  if (!path || !rgb || width < 1 || height < 1) { rt_set_error("rt_write_png: bad argument"); return RT_ERR_ARG; }
+  const size_t row = (size_t)width * 3, raw_n = (row + 1) * (size_t)height;
+  std::vector<uint8_t> z; z.reserve(raw_n + raw_n / 65535 * 5 + 16);
+  z.push_back(0x78); z.push_back(0x01);
+  uint32_t a = 1, b = 0;   // Adler-32 over the filtered scanlines
+  std::vector<uint8_t> raw(raw_n);
+  for (int y = 0; y < height; y++) { raw[(row + 1) * y] = 0; memcpy(&raw[(row + 1) * y + 1], rgb + row * y, row); }
+  for (size_t i = 0; i < raw_n;) {
+    const size_t n = std::min<size_t>(5552, raw_n - i);
+    for (size_t k = 0; k < n; k++) { a += raw[i + k]; b += a; }
+    a %= 65521; b %= 65521; i += n;
+  }
+  for (size_t i = 0; i < raw_n;) {
+    const size_t n = std::min<size_t>(65535, raw_n - i);
+    z.push_back(i + n == raw_n ? 1 : 0);
+    z.push_back(n & 0xFF); z.push_back(n >> 8); z.push_back(~n & 0xFF); z.push_back((~n >> 8) & 0xFF);
+    z.insert(z.end(), raw.begin() + i, raw.begin() + i + n);
+    i += n;
+  }
+  put_be32(z, (b << 16) | a);
+  std::vector<uint8_t> out = {0x89, 'P', 'N', 'G', 0x0D, 0x0A, 0x1A, 0x0A};
+  std::vector<uint8_t> ihdr; put_be32(ihdr, (uint32_t)width); put_be32(ihdr, (uint32_t)height);
+  ihdr.push_back(8); ihdr.push_back(2); ihdr.push_back(0); ihdr.push_back(0); ihdr.push_back(0);
+  png_chunk(out, "IHDR", ihdr); png_chunk(out, "IDAT", z); png_chunk(out, "IEND", {});
+  FILE* f = fopen(path, "wb");
+  if (!f) { rt_set_error(std::string("cannot write ") + path); return RT_ERR_IO; }
+  const size_t w = fwrite(out.data(), 1, out.size(), f);
+  fclose(f);
+  if (w != out.size()) { rt_set_error(std::string("short write to ") + path); return RT_ERR_IO; }
+  return RT_OK;
+}

@@ -1,0 +1,79 @@
+// rt_internal.h -- data layout shared by the host scene builder and the HIP kernels.
+#ifndef RT_INTERNAL_H
+#define RT_INTERNAL_H
+
+#include <cstdint>
+#include <string>
+#include <vector>
+
+#include "../../include/rt_amd.h"
+
+// Constants of the reference path (model/model.cuh:21-25, camera/camera.cuh:5,
+// octtree/octtree.cu:17, ray/ray.cuh:10,16, octtree/octtree.cuh:23).
+#define RT_INF 64.0f
+#define RT_EPS 0.001f
+#define RT_NEAR 0.1f
+#define RT_LEAF_CAP 50
+#define RT_RAY_STACK 10
+#define RT_OCT_STACK 20
+#define RT_MAX_LEVELS 3
+
+enum RtMatType { RT_LAMBERT = 0, RT_PHONG = 1, RT_REFLECTIVE = 2, RT_DIELECTRIC = 3 };
+enum RtLightType { RT_PUNCTUAL = 0, RT_SPOT = 1, RT_AMBIENT = 2, RT_DIRECTIONAL = 3 };
+
+// 96 B, passed to kernels by value (lives in SGPRs / kernarg, never re-read from HBM per pixel).
+struct RtCamera {
+  float u[3], v[3], w[3], pos[3];
+  float left, right, bottom, top;
+  float scene_refr, bg[3];
+  int32_t width, height, max_depth, shadows;
+};
+
+struct RtMaterial {   // 32 B
+  float col[3]; float param;
+  float att[3]; int32_t type;
+};
+
+struct RtLight {      // 48 B
+  float col[3]; int32_t type;
+  float pos[3]; float angle;
+  float dir[3]; float cos_half;   // cosf(angle/2), evaluated once on the host (lights.cu:289,343 evaluate it per call)
+};
+
+struct RtSphere {     // 32 B
+  float c[3], r;
+  int32_t mat_first, mat_count, pad0, pad1;
+};
+
+// Octree node, 32 B = two 16-byte loads.  Children of a branch are eight
+// consecutive records starting at `first`.
+//   a = ini.x ini.y ini.z bits(first)   first: branch -> index of child 0, leaf -> offset into leaf_refs
+//   b = end.x end.y end.z bits(count)   count: branch -> -1, leaf -> number of triangles (0..50)
+struct RtNode { float a[4]; float b[4]; };
+
+// Triangle intersection record, 48 B = three 16-byte loads:
+//   v0.xyz, e1.xyz, e2.xyz (e1 = v1 - v0, e2 = v2 - v0 rounded to float, the first
+//   six operations of triangle.cu:118-120), then mesh index and two pads.
+struct RtTriGeom { float v0[3]; float e1[3]; float e2[3]; int32_t mesh; int32_t pad[2]; };
+
+// Triangle shading record, 64 B, read once per closest hit: v1, v2 and the three vertex normals.
+struct RtTriShade { float v1[3]; float v2[3]; float n0[3]; float n1[3]; float n2[3]; float pad; };
+
+struct rt_scene {
+  RtCamera cam;
+  std::vector<RtMaterial> materials;
+  std::vector<RtLight> lights;
+  std::vector<RtSphere> spheres;
+  std::vector<int32_t> mat_index;                 // concatenated material lists (spheres, then meshes)
+  std::vector<int32_t> mesh_mat_first, mesh_mat_count;
+  std::vector<RtNode> nodes;                      // nodes[0] = root (always a branch) when non-empty
+  std::vector<int32_t> leaf_refs;
+  std::vector<RtTriGeom> tri_geom;
+  std::vector<RtTriShade> tri_shade;
+  std::vector<float> tri_verts, tri_normals;      // n*9 each, as the reference uploads them
+  rt_scene_info info;
+};
+
+void rt_set_error(const std::string& msg);
+
+#endif
