@@ -58,6 +58,22 @@ class Stats(C.Structure):
 _lib = None
 
 
+def _share_hip_runtime_with_torch():
+    """PyTorch wheels bundle their own libamdhip64.so (soname libamdhip64.so.7, the soname librt_amd.so
+    asks for).  Two HIP runtimes in one process cannot both own the GPU, so when torch is installed its
+    copy is loaded first and librt_amd.so binds to it; torch imported later finds the same file."""
+    import importlib.util
+    try:
+        spec = importlib.util.find_spec("torch")
+    except (ImportError, ValueError):
+        spec = None
+    if spec is None or not spec.origin:
+        return
+    cand = os.path.join(os.path.dirname(spec.origin), "lib", "libamdhip64.so")
+    if os.path.exists(cand):
+        C.CDLL(cand, mode=C.RTLD_GLOBAL)
+
+
 def lib():
     """Load librt_amd.so; raise loudly when it has not been built (there is no fallback)."""
     global _lib
@@ -65,6 +81,7 @@ def lib():
         if not os.path.exists(LIB_PATH):
             raise ImportError("%s is missing: run `make` (or __graft_entry__.build()) first; "
                               "raytracer_amd has no non-HIP rendering path" % LIB_PATH)
+        _share_hip_runtime_with_torch()
         L = C.CDLL(LIB_PATH)
         L.rt_scene_load.argtypes = [C.c_char_p, C.c_char_p, C.c_char_p, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_void_p)]
         L.rt_scene_destroy.argtypes = [C.c_void_p]
