@@ -54,19 +54,22 @@ typedef struct rt_scene_info {
 } rt_scene_info;
 
 /* Work counters of one render call.  rays = calls of the closest-hit routine
- * (primary + bounce + shadow), the unit of the Mrays/s metric.  The four
- * *_tests counters are only filled by rt_render_rows when RT_RENDER_COUNT_TESTS
- * is set (instrumented kernel variant). */
+ * (primary + bounce + shadow) the reference performs for these pixels, the unit
+ * of the Mrays/s metric.  The four *_tests counters are only filled when
+ * RT_RENDER_COUNT_TESTS is set (instrumented kernel variant, which also walks
+ * every shadow ray to the end as the reference does). */
 typedef struct rt_stats {
   uint64_t rays, shadow_rays;
   uint64_t node_tests, leaf_visits, tri_tests, sphere_tests;
   uint64_t ub_leave_level0, ub_level_overflow, ub_stack_overflow;
+  uint64_t rays_traced;   /* traversals actually run: one shadow ray serves every material of a hit point */
   float kernel_ms;   /* HIP-event time of the render kernels of this call (0 unless RT_RENDER_TIME) */
 } rt_stats;
 
 enum {
   RT_RENDER_COUNT_TESTS = 1,  /* run the instrumented variant that counts node / leaf / triangle / sphere tests */
-  RT_RENDER_TIME = 2          /* bracket the kernels with HIP events on `stream` and synchronise */
+  RT_RENDER_TIME = 2,         /* bracket the kernels with HIP events on `stream` and synchronise */
+  RT_RENDER_LITERAL = 4       /* cross-check kernel: one private stack per pixel, the reference's solves evaluated as written */
 };
 
 /* Parse resources + scene, load and transform meshes, build the octree.

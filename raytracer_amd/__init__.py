@@ -20,6 +20,7 @@ LIB_PATH = os.path.join(_HERE, "librt_amd.so")
 
 RT_RENDER_COUNT_TESTS = 1
 RT_RENDER_TIME = 2
+RT_RENDER_LITERAL = 4
 
 # Every symbol include/rt_amd.h declares.
 ABI_SYMBOLS = (
@@ -49,7 +50,7 @@ class SceneInfo(C.Structure):
 class Stats(C.Structure):
     _fields_ = [(n, C.c_uint64) for n in (
         "rays", "shadow_rays", "node_tests", "leaf_visits", "tri_tests", "sphere_tests", "ub_leave_level0",
-        "ub_level_overflow", "ub_stack_overflow")] + [("kernel_ms", C.c_float)]
+        "ub_level_overflow", "ub_stack_overflow", "rays_traced")] + [("kernel_ms", C.c_float)]
 
     def as_dict(self):
         return {n: getattr(self, n) for n, _ in self._fields_}

@@ -622,7 +622,13 @@ void load_scene_into(rt_scene& sc, const std::string& scene_path, const std::str
   rt_scene_info& I = sc.info; memset(&I, 0, sizeof I);
   I.parse_seconds = seconds_since(t_parse);
   const auto t_build = Clock::now();
-  if (!mesh_mats.empty()) { TreeBuilder tb(sc); tb.build(); }
+  if (!mesh_mats.empty()) {
+    TreeBuilder tb(sc); tb.build();
+    // Leaf-ordered copy of the intersection records: a leaf's triangles are one contiguous run, so the
+    // traversal streams them without the index indirection.
+    sc.tri_leaf.resize(sc.leaf_refs.size());
+    for (size_t r = 0; r < sc.leaf_refs.size(); r++) { sc.tri_leaf[r] = sc.tri_geom[sc.leaf_refs[r]]; sc.tri_leaf[r].mesh = sc.leaf_refs[r]; }
+  }
   I.build_seconds = seconds_since(t_build);
   I.width = W; I.height = H; I.max_depth = depth;
   I.n_triangles = (int32_t)sc.tri_geom.size(); I.n_spheres = (int32_t)sc.spheres.size();

@@ -69,6 +69,7 @@ struct rt_scene {
   std::vector<RtNode> nodes;                      // nodes[0] = root (always a branch) when non-empty
   std::vector<int32_t> leaf_refs;
   std::vector<RtTriGeom> tri_geom;
+  std::vector<RtTriGeom> tri_leaf;                // tri_geom records repeated in leaf order (index space of leaf_refs); `mesh` holds the triangle id
   std::vector<RtTriShade> tri_shade;
   std::vector<float> tri_verts, tri_normals;      // n*9 each, as the reference uploads them
   rt_scene_info info;

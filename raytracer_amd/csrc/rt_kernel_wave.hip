@@ -1,0 +1,385 @@
+// rt_kernel_wave.hip -- wave-synchronous render kernel for gfx950.
+//
+// A 64-lane wave owns an 8x8 pixel tile and walks the octree ONCE for all of its rays.  The
+// reference visits children in the fixed order 0..7 whatever the ray direction (ray.cu:40-50), so
+// every ray of the wave meets the nodes of the union of their subtrees in the same order; the wave
+// therefore keeps one traversal stack (node, next child, 64-bit mask of the lanes that entered the
+// node) instead of 64.  Consequences on CDNA4:
+//   * node and triangle records are addressed with wave-uniform indices, i.e. fetched through the
+//     scalar cache into SGPRs once per wave, and the loop control runs on the scalar unit;
+//   * a triangle is tested by all interested lanes in the same iteration, so the tests share
+//     wave-level early-outs (ballot == 0 -> skip the rest of the solve);
+//   * each lane still takes exactly the decisions of its own depth-first walk with its own running
+//     closest t, which is what makes the result identical to the reference's.
+// Neighbouring pixels of a tile traverse nearly the same subtree (measured on meshDragon at 4K: the
+// union costs 1.02x the node tests and 0.80x the triangle iterations of 64 private stacks).
+//
+// Decisions are taken with the division-free predicates of rt_math.h; quotients are formed only for
+// triangles that pass every sign / range test.  Built with -ffp-contract=off.
+#include "rt_kernels.h"
+
+namespace {
+
+struct Tally { uint32_t rays, shadow, node, leaf, tri, sph, traced; };
+
+// The wave's traversal stack lives in four VGPRs: entry i is held by lane i (depth <= 20 < 64) and is
+// written with a lane-select and read with v_readlane, whose lane index is wave-uniform.  No LDS, no memory latency.
+struct WaveStack {
+  uint32_t first, cur, mask_lo, mask_hi;   // index of child 0 of the branch, next child to test, lanes that entered it
+};
+
+__device__ __forceinline__ uint32_t uni(uint32_t v) { return __builtin_amdgcn_readfirstlane(v); }
+__device__ __forceinline__ uint64_t uni64(uint64_t v) {
+  return ((uint64_t)uni((uint32_t)(v >> 32)) << 32) | uni((uint32_t)v);
+}
+
+// Closest hit (ray.cu:29-54) for all lanes of the wave at once.
+//   want   : this lane has a ray to trace
+//   stop_t : >= 0 for a shadow ray: the lane drops out as soon as its t falls below stop_t, because
+//            only "t < light distance" is consumed (ray.cu:70) and t never grows; < 0 = never
+template <bool COUNT>
+__device__ __forceinline__ void trace_wave(const float4* __restrict__ nodes, const float4* __restrict__ tri_leaf,
+                                           const RtSphere* __restrict__ spheres, int n_spheres, bool has_oct, bool want,
+                                           const RtVec3& e, const RtVec3& d, float stop_t, Hit& hit, WaveStack& st,
+                                           int lane, Tally& tl) {
+  const uint64_t lane_bit = 1ull << lane;
+  uint64_t live = __ballot(want);
+  if (!live) return;
+  const RtRayConst rc = rt_ray_const(d);
+  RtTConst tc = rt_t_const(rc, hit.t);
+  bool mine_live = want;
+
+  if (has_oct) {
+    uint32_t top_first = uni(__float_as_uint(nodes[0].w)), top_cur = 0;   // the root is entered without a test (ray.cu:36-38)
+    uint64_t top_mask = live;
+    int sp = 0;
+    for (;;) {
+      if (top_cur == 8u || (top_mask & live) == 0ull) {   // branch exhausted, or every lane that entered it is decided
+        if (sp == 0) break;
+        sp--;
+        top_first = __builtin_amdgcn_readlane(st.first, sp); top_cur = __builtin_amdgcn_readlane(st.cur, sp);
+        top_mask = ((uint64_t)(uint32_t)__builtin_amdgcn_readlane(st.mask_hi, sp) << 32) | (uint32_t)__builtin_amdgcn_readlane(st.mask_lo, sp);
+        continue;
+      }
+      const uint32_t child = top_first + top_cur;
+      top_cur++;
+      const float4 na = nodes[2 * child], nb = nodes[2 * child + 1];
+      const bool mine = mine_live && (top_mask & lane_bit) != 0ull;
+      if (COUNT && mine) tl.node++;
+      const bool acc = mine & rt_node_accept_exact({na.x, na.y, na.z}, {nb.x, nb.y, nb.z}, e, d, rc, tc);
+      const uint64_t m = __ballot(acc);
+      if (!m) continue;
+      const uint32_t first = uni(__float_as_uint(na.w));
+      const int32_t count = (int32_t)uni(__float_as_uint(nb.w));
+      if (count < 0) {   // branch: descend; the parent is only kept if it has children left
+        if (top_cur < 8u) {
+          const bool slot = lane == sp;   // lane sp keeps entry sp
+          st.first = slot ? top_first : st.first; st.cur = slot ? top_cur : st.cur;
+          st.mask_lo = slot ? (uint32_t)top_mask : st.mask_lo; st.mask_hi = slot ? (uint32_t)(top_mask >> 32) : st.mask_hi;
+          sp++;
+        }
+        top_first = first; top_cur = 0; top_mask = m;
+        continue;
+      }
+      // leaf: every triangle in insertion order (octtree.cu:264-274); all lanes in `m` test the same triangle
+      if (COUNT && acc) { tl.leaf++; tl.tri += (uint32_t)count; }
+      bool changed = false;
+      for (int32_t k = 0; k < count; k++) {
+        const uint32_t r = first + (uint32_t)k;
+        const float4 g0 = tri_leaf[3 * r], g1 = tri_leaf[3 * r + 1], g2 = tri_leaf[3 * r + 2];
+        const RtVec3 v0 = {g0.x, g0.y, g0.z}, e1 = {g0.w, g1.x, g1.y}, e2 = {g1.z, g1.w, g2.x};
+        // stage 1: determinant and beta numerator (triangle.cu:117-131, first column of cofactors)
+        const RtVec3 b = {e.x - v0.x, e.y - v0.y, e.z - v0.z};
+        const RtVec3 c2 = {-d.x, -d.y, -d.z};
+        const float m00 = e2.y * c2.z - c2.y * e2.z;
+        const float m10 = -e2.x * c2.z + e2.z * c2.x;
+        const float m20 = e2.x * c2.y - e2.y * c2.x;
+        RtTriNum n;
+        n.det = e1.x * m00 + e1.y * m10 + e1.z * m20;
+        n.nb = m00 * b.x + m10 * b.y + m20 * b.z;
+        const unsigned s = rt_bits(n.det) & 0x80000000u;
+        const float ad = fabsf(n.det);
+        const float nbs = rt_from_bits(rt_bits(n.nb) ^ s);
+        bool pass = acc & (ad > 0.f) & (nbs >= 0.f) & (nbs <= ad);
+        if (!__ballot(pass)) continue;
+        // stage 2: gamma numerator
+        const float m01 = -e1.y * c2.z + e1.z * c2.y;
+        const float m11 = e1.x * c2.z - e1.z * c2.x;
+        const float m21 = -e1.x * c2.y + e1.y * c2.x;
+        n.ng = m01 * b.x + m11 * b.y + m21 * b.z;
+        const float ngs = rt_from_bits(rt_bits(n.ng) ^ s);
+        pass = pass & (ngs >= 0.f) & (ngs <= ad);
+        if (!__ballot(pass)) continue;
+        // stage 3: t numerator; t > 0, and t clearly beyond the closest hit is rejected without dividing
+        const float m02 = e1.y * e2.z - e1.z * e2.y;
+        const float m12 = -e1.x * e2.z + e1.z * e2.x;
+        const float m22 = e1.x * e2.y - e1.y * e2.x;
+        n.nt = m02 * b.x + m12 * b.y + m22 * b.z;
+        const float nts = rt_from_bits(rt_bits(n.nt) ^ s);
+        pass = pass & (nts > 0.f) & (nts <= (hit.t * ad) * 1.000001f);
+        if (!__ballot(pass)) continue;
+        if (pass) {   // the reference's quotients decide (triangle.cu:131-137)
+          float t, bet, gam;
+          if (rt_triangle_finish(n, hit.t, t, bet, gam)) {
+            hit.t = t; hit.prim = (int32_t)__float_as_uint(g2.y); hit.bet = bet; hit.gam = gam;
+            changed = true;
+          }
+        }
+      }
+      if (__ballot(changed)) {
+        if (changed) {
+          tc = rt_t_const(rc, hit.t);
+          if (stop_t >= 0.f && hit.t < stop_t) mine_live = false;
+        }
+        live = __ballot(mine_live);
+        if (!live) return;
+      }
+    }
+  }
+  for (int32_t s = 0; s < n_spheres; s++) {   // ray.cu:52-53
+    if (mine_live) {
+      if (COUNT) tl.sph++;
+      if (rt_sphere_test(ld3(spheres[s].c), spheres[s].r, e, d, hit.t)) {
+        hit.prim = -2 - s;
+        if (stop_t >= 0.f && hit.t < stop_t) mine_live = false;
+      }
+    }
+  }
+}
+
+enum { PH_CLOSEST = 0, PH_SHADOW = 1, PH_DONE = 2, PH_SHADE = 3 };
+
+template <bool BOUNCE, bool COUNT>
+__global__ __launch_bounds__(RT_BLOCK) void render_wave(
+    const RtCamera cam, const RowMap rows, const float4* __restrict__ nodes, const float4* __restrict__ tri_leaf,
+    const float4* __restrict__ tri_geom, const float4* __restrict__ tri_shade, const RtSphere* __restrict__ spheres,
+    const RtLight* __restrict__ lights, const RtMaterial* __restrict__ materials, const int32_t* __restrict__ mat_index,
+    const int32_t* __restrict__ mesh_mat_first, const int32_t* __restrict__ mesh_mat_count, int n_spheres, int n_lights, int has_oct,
+    uint8_t* __restrict__ rgb, int32_t* __restrict__ ids, float* __restrict__ ts, unsigned long long* __restrict__ counters) {
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  WaveStack st = {0u, 0u, 0u, 0u};
+  const int W = cam.width, H = cam.height;
+  const int col = blockIdx.x * RT_TILE_W + (wave & 1) * 8 + (lane & 7);
+  const int lrow = blockIdx.y * RT_TILE_H + (wave >> 1) * 8 + (lane >> 3);
+  const int row = rows.row0 + (lrow / rows.band_rows) * rows.band_stride + lrow % rows.band_rows;
+  const int orow = rows.compact ? lrow : row;
+  const bool valid = col < W && lrow < rows.n_local && row < H;
+  Tally tl = {0, 0, 0, 0, 0, 0, 0};
+  const RtCamera& c = cam;
+
+  // view handed to the helpers of rt_kernels.h
+  RtDeviceView S;
+  S.tri_geom = tri_geom; S.tri_shade = tri_shade; S.spheres = spheres;
+
+  // ---- per-lane path state -------------------------------------------------------------------
+  BounceRay cur;   // ray being shaded (or traced, in PH_CLOSEST)
+  {
+    const int i = col, j = H - 1 - row;   // camera.cu:94,118: j counts from the bottom
+    // camera.cu:96-99; (i+0.5) is a double, so product and sum are double before the store to float
+    const float ic = (float)((double)c.left + (double)((c.right - c.left) / (float)(unsigned short)W) * ((double)i + 0.5));
+    const float jc = (float)((double)c.bottom + (double)((c.top - c.bottom) / (float)(unsigned short)H) * ((double)j + 0.5));
+    const float kz = -RT_NEAR;
+    RtVec3 d0 = {ic * c.u[0] + jc * c.v[0] + kz * c.w[0], ic * c.u[1] + jc * c.v[1] + kz * c.w[1], ic * c.u[2] + jc * c.v[2] + kz * c.w[2]};
+    cur.dir = rt_normalized(d0);
+    cur.eye = {c.pos[0], c.pos[1], c.pos[2]}; cur.att = {1.f, 1.f, 1.f};
+    cur.level[0] = c.scene_refr; cur.level[1] = 0.f; cur.level[2] = 0.f; cur.nlevel = 0; cur.depth = 0;
+  }
+  BounceRay rstack[BOUNCE ? RT_RAY_STACK : 1];
+  int rsp = 0;
+  int phase = valid ? PH_CLOSEST : PH_DONE;
+  bool primary = true;
+  float color[3] = {0.f, 0.f, 0.f}, colr[3] = {0.f, 0.f, 0.f};
+  Hit hit = {RT_INF, -1, 0.f, 0.f};        // closest hit of `cur`
+  RtVec3 P = {0, 0, 0}, N = {0, 0, 1};
+  int32_t mfirst = 0, mcount = 0, mi = 0, li = 0;
+  uint32_t vis_known = 0, vis_occluded = 0;   // per light (first 32): shadow test already traced for this hit point
+  RtVec3 sray_e = {0, 0, 0}, sray_d = {0, 0, 1}; float sray_len = 0.f;   // pending shadow ray
+  int verdict = -1;                                                        // result of the last shadow ray, until consumed
+
+  while (__ballot(phase != PH_DONE)) {
+    // ---- trace the pending rays of the wave ---------------------------------------------------
+    {
+      const bool want = phase != PH_DONE;
+      const bool is_shadow = phase == PH_SHADOW;
+      Hit h = {RT_INF, -1, 0.f, 0.f};
+      const RtVec3 te = is_shadow ? sray_e : cur.eye, td = is_shadow ? sray_d : cur.dir;
+      // the instrumented variant walks shadow rays to the end, as the reference does, so that its test counts match
+      const float stop_t = (is_shadow && !COUNT) ? sray_len : -1.f;
+      if (want) tl.traced++;
+      trace_wave<COUNT>(nodes, tri_leaf, spheres, n_spheres, has_oct != 0, want, te, td, stop_t, h, st, lane, tl);
+      if (phase == PH_CLOSEST) {
+        hit = h;
+        if (primary) {
+          primary = false;
+          const size_t p = (size_t)orow * W + col;
+          if (ids) ids[p] = hit.prim;
+          if (ts) ts[p] = hit.t;
+        }
+        colr[0] = colr[1] = colr[2] = 0.f;
+        mi = 0; li = 0; vis_known = 0; vis_occluded = 0;
+        if (hit.prim == -1) {
+          colr[0] = c.bg[0]; colr[1] = c.bg[1]; colr[2] = c.bg[2];   // ray.cu:86
+          mcount = 0;
+        } else {
+          surface(S, cur.eye, cur.dir, hit, P, N);
+          if (hit.prim >= 0) {
+            const int32_t mesh = (int32_t)__float_as_uint(tri_geom[3 * hit.prim + 2].y);
+            mfirst = mesh_mat_first[mesh]; mcount = mesh_mat_count[mesh];
+          } else { mfirst = spheres[-2 - hit.prim].mat_first; mcount = spheres[-2 - hit.prim].mat_count; }
+        }
+      } else if (phase == PH_SHADOW) {
+        verdict = sray_len > h.t ? 1 : 0;   // ray.cu:70; consumed by the (material, light) step that asked for it
+      }
+    }
+    // ---- shade until the lane needs another ray or its pixel is finished ------------------------
+    if (phase != PH_DONE) {
+      phase = PH_SHADE;
+      while (phase == PH_SHADE) {
+        if (mi >= mcount) {   // every material of the hit handled: camera.cu:110-111, then next ray of the pixel
+          color[0] = color[0] + cur.att.x * colr[0];
+          color[1] = color[1] + cur.att.y * colr[1];
+          color[2] = color[2] + cur.att.z * colr[2];
+          if (BOUNCE && rsp > 0) { cur = rstack[--rsp]; phase = PH_CLOSEST; tl.rays++; }
+          else phase = PH_DONE;
+          break;
+        }
+        const RtMaterial M = materials[mat_index[mfirst + mi]];
+        if (M.type == RT_LAMBERT || M.type == RT_PHONG) {   // material.cu:15-24, lights.cu:260-367
+          if (li >= n_lights) { mi++; li = 0; continue; }
+          const RtLight L = lights[li];
+          if (L.type == RT_AMBIENT) {
+            if (M.type == RT_LAMBERT) for (int k = 0; k < 3; k++) colr[k] = colr[k] + M.col[k] * L.col[k];
+            li++; continue;
+          }
+          RtVec3 l; float ldist;
+          if (L.type == RT_DIRECTIONAL) { l = {L.dir[0] * -1, L.dir[1] * -1, L.dir[2] * -1}; ldist = RT_INF; }
+          else l = rt_normalized({L.pos[0] - P.x, L.pos[1] - P.y, L.pos[2] - P.z});
+          const RtVec3 sP = {P.x + l.x * RT_EPS, P.y + l.y * RT_EPS, P.z + l.z * RT_EPS};
+          if (L.type != RT_DIRECTIONAL) ldist = rt_len({L.pos[0] - sP.x, L.pos[1] - sP.y, L.pos[2] - sP.z});
+          if (c.shadows) {   // ray.cu:56-72
+            bool occluded;
+            if (verdict >= 0) {   // the trace requested by this very step has come back
+              occluded = verdict != 0; verdict = -1;
+              if (!COUNT && li < 32) { vis_known |= 1u << li; if (occluded) vis_occluded |= 1u << li; }
+            } else if (!COUNT && li < 32 && ((vis_known >> li) & 1u)) {
+              // origin, direction and length depend on the hit point and the light only, so every further
+              // material of this hit gets the verdict of the ray already traced (the instrumented variant
+              // re-traces, to count what the reference does)
+              occluded = (vis_occluded >> li) & 1u;
+            } else {
+              sray_e = sP; sray_d = l; sray_len = ldist; phase = PH_SHADOW;
+              break;
+            }
+            tl.rays++; tl.shadow++;   // the reference casts this ray for every (material, light) pair
+            if (occluded) { li++; continue; }
+          }
+          if (L.type == RT_SPOT && !(-rt_dot(l, ld3(L.dir)) > L.cos_half)) { li++; continue; }
+          float w;
+          if (M.type == RT_LAMBERT) { const float nl = rt_dot(N, l); w = nl > 0.f ? nl : 0.f; }
+          else {
+            const RtVec3 h = rt_normalized({cur.dir.x * -1 + l.x, cur.dir.y * -1 + l.y, cur.dir.z * -1 + l.z});
+            const float nh = rt_dot(N, h);
+            w = powf(nh > 0.f ? nh : 0.f, M.param);
+          }
+          for (int k = 0; k < 3; k++) colr[k] = colr[k] + (M.col[k] * L.col[k]) * w;
+          li++;
+        } else {
+          if (BOUNCE && cur.depth < c.max_depth) {
+            const float s2 = 2 * rt_dot(cur.dir, N);
+            const RtVec3 rl = rt_normalized({cur.dir.x - N.x * s2, cur.dir.y - N.y * s2, cur.dir.z - N.z * s2});
+            if (M.type == RT_REFLECTIVE) {   // material.cu:25-35
+              if (rsp < RT_RAY_STACK) {
+                BounceRay& r = rstack[rsp++];
+                r.eye = {P.x + rl.x * RT_EPS, P.y + rl.y * RT_EPS, P.z + rl.z * RT_EPS}; r.dir = rl;
+                r.att = {M.col[0] * cur.att.x, M.col[1] * cur.att.y, M.col[2] * cur.att.z};
+                for (int k = 0; k < 3; k++) r.level[k] = cur.level[k];
+                r.nlevel = cur.nlevel; r.depth = cur.depth + 1;
+              } else atomicAdd(&counters[C_UB_STACK], 1ull);
+            } else {   // RT_DIELECTRIC, material.cu:36-99
+              const float refr = cur.level[cur.nlevel];
+              const RtVec3 rlsP = {P.x + N.x * RT_EPS, P.y + N.y * RT_EPS, P.z + N.z * RT_EPS};
+              const float q = (refr - M.param) / (refr + M.param);
+              const float R0 = q * q;
+              const float dn = rt_dot(cur.dir, N);
+              const bool entering = dn < 0;
+              float rOrI, cs; RtVec3 nn; float K[3];
+              if (entering) { rOrI = refr / M.param; cs = -dn; nn = N; K[0] = K[1] = K[2] = 1.0f; }
+              else {
+                rOrI = M.param / refr; cs = dn; nn = {N.x * -1, N.y * -1, N.z * -1};
+                for (int k = 0; k < 3; k++) K[k] = expf(M.att[k] * -hit.t);
+              }
+              const float totRefl = 1 - (rOrI * rOrI) * (1 - cs * cs);
+              const float a3[3] = {cur.att.x, cur.att.y, cur.att.z};
+              float attl[3], attf[3];
+              for (int k = 0; k < 3; k++) { attl[k] = (M.col[k] * K[k]) * a3[k]; attf[k] = attl[k]; }
+              if (totRefl >= 0) {
+                const RtVec3 rf = refract_dir(cur.dir, nn, rOrI);
+                const float fresnel = (float)((double)R0 + (double)(1 - R0) * pow(1.0 - (double)cs, 5.0));
+                for (int k = 0; k < 3; k++) attf[k] = attf[k] * (1 - fresnel);
+                int nl;
+                if (entering) {
+                  nl = cur.nlevel + 1;
+                  if (nl > 2) { nl = 2; atomicAdd(&counters[C_UB_OVER], 1ull); }
+                  cur.level[nl] = M.param;
+                } else {
+                  nl = cur.nlevel - 1;
+                  if (nl < 0) { nl = 0; atomicAdd(&counters[C_UB_LEAVE], 1ull); }
+                }
+                if (rsp < RT_RAY_STACK) {
+                  BounceRay& r = rstack[rsp++];
+                  r.eye = {P.x + rf.x * RT_EPS, P.y + rf.y * RT_EPS, P.z + rf.z * RT_EPS}; r.dir = rf;
+                  r.att = {attf[0], attf[1], attf[2]};
+                  for (int k = 0; k < 3; k++) r.level[k] = cur.level[k];
+                  r.nlevel = nl; r.depth = cur.depth + 1;
+                } else atomicAdd(&counters[C_UB_STACK], 1ull);
+                for (int k = 0; k < 3; k++) attl[k] = attl[k] * fresnel;
+              }
+              if (rsp < RT_RAY_STACK) {
+                BounceRay& r = rstack[rsp++];
+                r.eye = rlsP; r.dir = rl; r.att = {attl[0], attl[1], attl[2]};
+                for (int k = 0; k < 3; k++) r.level[k] = cur.level[k];
+                r.nlevel = cur.nlevel; r.depth = cur.depth + 1;
+              } else atomicAdd(&counters[C_UB_STACK], 1ull);
+            }
+          }
+          mi++; li = 0;
+        }
+      }
+    }
+  }
+
+  if (valid) {
+    const size_t p = ((size_t)orow * W + col) * 3;
+    for (int k = 0; k < 3; k++) {   // camera.cu:113-122; NaN < 1 is false, so NaN -> 1 -> 255
+      const float v = (color[k] < 1.f ? color[k] : 1.f) * 255.f;
+      rgb[p + k] = v < 0.f ? (uint8_t)0 : (uint8_t)(int)v;
+    }
+    tl.rays++;   // the primary ray
+  }
+
+  // work counters: wave reduction, one atomic per wave and counter
+  const uint32_t vals[7] = {tl.rays, tl.shadow, tl.node, tl.leaf, tl.tri, tl.sph, tl.traced};
+  const int slot[7] = {C_RAYS, C_SHADOW, C_NODE, C_LEAF, C_TRI, C_SPH, C_TRACED};
+  for (int k = 0; k < 7; k++) {
+    if (!COUNT && k >= 2 && k <= 5) continue;
+    uint32_t v = vals[k];
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+    if (lane == 0 && v) atomicAdd(&counters[slot[k]], (unsigned long long)v);
+  }
+}
+
+}  // namespace
+
+void rt_launch_wave_kernel(const RtDeviceView& V, const RowMap& rows, bool bounce, bool count, uint8_t* rgb, int32_t* ids,
+                           float* ts, unsigned long long* counters, hipStream_t stream) {
+  const dim3 grid((V.cam.width + RT_TILE_W - 1) / RT_TILE_W, (rows.n_local + RT_TILE_H - 1) / RT_TILE_H), block(RT_BLOCK);
+#define LAUNCH(B, C)                                                                                                             \
+  hipLaunchKernelGGL((render_wave<B, C>), grid, block, 0, stream, V.cam, rows, V.nodes, V.tri_leaf, V.tri_geom, V.tri_shade,     \
+                     V.spheres, V.lights, V.materials, V.mat_index, V.mesh_mat_first, V.mesh_mat_count, V.n_spheres, V.n_lights, \
+                     V.has_oct, rgb, ids, ts, counters)
+  if (bounce && count) LAUNCH(true, true);
+  else if (bounce) LAUNCH(true, false);
+  else if (count) LAUNCH(false, true);
+  else LAUNCH(false, false);
+#undef LAUNCH
+}

@@ -1,0 +1,91 @@
+// rt_kernels.h -- declarations shared by the HIP translation units of the render path.
+#ifndef RT_KERNELS_H
+#define RT_KERNELS_H
+
+#include <hip/hip_runtime.h>
+
+#include "rt_internal.h"
+#include "rt_math.h"
+
+#define RT_BLOCK 256
+#define RT_TILE_W 16   // pixels per workgroup tile: four 8x8 wave tiles
+#define RT_TILE_H 16
+
+// Device-resident scene, passed to kernels by value.
+struct RtDeviceView {
+  RtCamera cam;
+  const float4* nodes;        // 2 per node
+  const int32_t* leaf_refs;
+  const float4* tri_geom;     // 3 per triangle, indexed by triangle id
+  const float4* tri_leaf;     // 3 per leaf reference, in leaf order (same index space as leaf_refs)
+  const float4* tri_shade;    // 4 per triangle
+  const RtSphere* spheres;
+  const RtLight* lights;
+  const RtMaterial* materials;
+  const int32_t* mat_index;
+  const int32_t* mesh_mat_first;
+  const int32_t* mesh_mat_count;
+  int32_t n_spheres, n_lights, has_oct, pad;
+};
+
+// Which image rows a launch renders and where they are stored.  Local row lr (0..n_local) is image
+// row  row0 + (lr / band_rows) * band_stride + lr % band_rows ; it is stored at image row position
+// when `compact` is 0 and at row lr of a band-packed buffer when it is 1.
+struct RowMap { int32_t row0, band_rows, band_stride, n_local, compact, pad; };
+
+enum { C_RAYS = 0, C_SHADOW, C_NODE, C_LEAF, C_TRI, C_SPH, C_UB_LEAVE, C_UB_OVER, C_UB_STACK, C_TRACED, C_COUNT };
+
+struct Hit {
+  float t;
+  int32_t prim;    // >=0 triangle, <=-2 sphere (-2 - index), -1 nothing yet
+  float bet, gam;  // barycentrics of the accepted triangle
+};
+
+struct BounceRay {   // the fields of DRay that survive a push (vector.cu:188-207)
+  RtVec3 eye, dir, att;
+  float level[RT_MAX_LEVELS];
+  int32_t nlevel, depth;
+};
+
+__device__ __forceinline__ RtVec3 ld3(const float* p) { return {p[0], p[1], p[2]}; }
+
+// Hit point and shading normal of the accepted primitive (triangle.cu:141-147, spheres.cu:92-93).
+__device__ __forceinline__ void surface(const RtDeviceView& S, const RtVec3& eye, const RtVec3& dir, const Hit& h,
+                                        RtVec3& P, RtVec3& N) {
+  if (h.prim >= 0) {
+    const float4 g0 = S.tri_geom[3 * h.prim];
+    const float4 s0 = S.tri_shade[4 * h.prim], s1 = S.tri_shade[4 * h.prim + 1], s2 = S.tri_shade[4 * h.prim + 2],
+                 s3 = S.tri_shade[4 * h.prim + 3];
+    const float alp = 1 - h.bet - h.gam, bet = h.bet, gam = h.gam;
+    const RtVec3 v0 = {g0.x, g0.y, g0.z}, v1 = {s0.x, s0.y, s0.z}, v2 = {s0.w, s1.x, s1.y};
+    const RtVec3 n0 = {s1.z, s1.w, s2.x}, n1 = {s2.y, s2.z, s2.w}, n2 = {s3.x, s3.y, s3.z};
+    N = {(n0.x * alp + n1.x * bet) + n2.x * gam, (n0.y * alp + n1.y * bet) + n2.y * gam, (n0.z * alp + n1.z * bet) + n2.z * gam};
+    N = rt_normalized(N);
+    P = {(v0.x * alp + v1.x * bet) + v2.x * gam, (v0.y * alp + v1.y * bet) + v2.y * gam, (v0.z * alp + v1.z * bet) + v2.z * gam};
+  } else {
+    const RtSphere& sp = S.spheres[-2 - h.prim];
+    P = {eye.x + dir.x * h.t, eye.y + dir.y * h.t, eye.z + dir.z * h.t};
+    N = rt_normalized({P.x - sp.c[0], P.y - sp.c[1], P.z - sp.c[2]});
+  }
+}
+
+// vector.cu:147-156
+__device__ __forceinline__ RtVec3 refract_dir(const RtVec3& d, const RtVec3& n, float rori) {
+  const float costhe = -rt_dot(d, n);
+  const float sinthe = sqrtf(1 - costhe * costhe);      // powf(x, 2) rounds to x*x
+  const float sinfi = rori * sinthe;
+  const float cosfi = sqrtf(1 - sinfi * sinfi);
+  RtVec3 r;
+  r.x = ((n.x * costhe + d.x) / sinthe) * sinfi - n.x * cosfi;
+  r.y = ((n.y * costhe + d.y) / sinthe) * sinfi - n.y * cosfi;
+  r.z = ((n.z * costhe + d.z) / sinthe) * sinfi - n.z * cosfi;
+  return r;
+}
+
+// Launchers (one per kernel family); all asynchronous on `stream`.
+void rt_launch_lane_kernel(const RtDeviceView& view, const RowMap& rows, bool bounce, bool count, uint8_t* rgb, int32_t* ids,
+                           float* ts, unsigned long long* counters, hipStream_t stream);
+void rt_launch_wave_kernel(const RtDeviceView& view, const RowMap& rows, bool bounce, bool count, uint8_t* rgb, int32_t* ids,
+                           float* ts, unsigned long long* counters, hipStream_t stream);
+
+#endif

@@ -100,4 +100,125 @@ RT_HD bool rt_sphere_test(const RtVec3& c, float r, const RtVec3& eye, const RtV
   return false;
 }
 
+// ------------------------------------------------------------------------------------------------
+// Division-free evaluation of the same accept / reject decisions.
+//
+// The reference decides with correctly rounded quotients q = fl(N / D) compared against 0, 1 and the
+// running closest t.  For finite floats, barring underflow of a quotient to zero:
+//   q >= 0      <=>  N and D agree in sign (or N is zero)
+//   q <= 1      <=>  |N| <= |D|          (no float lies in (|D|, |D|(1 + 2^-24)], the interval that rounds to 1)
+//   q <  T      <=>  N' < Tm * D'        (exact in double: Tm = midpoint of T and its predecessor, 25 x 24 bits;
+//                                          on a tie the quotient rounds to the neighbour with the even mantissa)
+// Octree boxes are cubes whose side is a power of two (root +-16 split at midpoints, octtree.cu:95), so
+// the extent factors of octtree.cu:295-313 scale numerators and denominators exactly and cancel:
+// a face on axis k crossed at t = fl(b_k / -d_k) has in-plane offset fl(P_i / d_k) with
+// P_i = fl(fl(d_k b_i) - fl(d_i b_k)), to be compared with 0 and the (signed) side.
+// ------------------------------------------------------------------------------------------------
+RT_HD unsigned rt_bits(float x) { union { float f; unsigned u; } c; c.f = x; return c.u; }
+RT_HD float rt_from_bits(unsigned u) { union { float f; unsigned u; } c; c.u = u; return c.f; }
+
+struct RtRayConst {        // per ray
+  float ad[3];             // |d_k|
+  unsigned sd[3];          // sign bit of d_k
+};
+struct RtTConst {          // per value of the running closest t
+  double td[3];            // Tm * |d_k|, one ulp higher when a tie counts as "less than T"
+  double tm;               // Tm itself (nudged the same way), for the triangle test
+};
+
+RT_HD RtRayConst rt_ray_const(const RtVec3& d) {
+  RtRayConst r;
+  r.ad[0] = fabsf(d.x); r.ad[1] = fabsf(d.y); r.ad[2] = fabsf(d.z);
+  r.sd[0] = rt_bits(d.x) & 0x80000000u; r.sd[1] = rt_bits(d.y) & 0x80000000u; r.sd[2] = rt_bits(d.z) & 0x80000000u;
+  return r;
+}
+
+RT_HD double rt_next_up(double p) {   // p >= 0 finite -> next double above; NaN stays NaN
+  union { double f; unsigned long long u; } c; c.f = p; c.u += 1ull; return c.f;
+}
+
+// T > 0.
+RT_HD RtTConst rt_t_const(const RtRayConst& r, float T) {
+  const unsigned pb = rt_bits(T) - 1u;                  // predecessor of T
+  const double tm = 0.5 * ((double)T + (double)rt_from_bits(pb));
+  const bool tie_is_less = (pb & 1u) == 0u;            // the midpoint rounds to the predecessor
+  RtTConst k;
+  for (int a = 0; a < 3; a++) {
+    const double p = tm * (double)r.ad[a];
+    k.td[a] = tie_is_less ? rt_next_up(p) : p;
+  }
+  k.tm = tm;   // ties for the triangle test are resolved at the use site (the product there is not exact in general)
+  return k;
+}
+
+// One face: plane axis k with b_k = e_k - plane; in-plane axes i, j with b measured from the face's
+// first vertex; neg_i / neg_j = 0x80000000 when the side runs in the negative direction from that vertex.
+RT_HD bool rt_face_exact(float dk_bi, float di_bk, float dk_bj, float dj_bk, float bk, unsigned sdk, unsigned neg_i,
+                         unsigned neg_j, float side_adk, double tdk) {
+  const float bpp = rt_from_bits(rt_bits(bk) ^ sdk ^ 0x80000000u);      // b_k * sign(-d_k): t > 0 <=> bpp > 0
+  const float qi = rt_from_bits(rt_bits(dk_bi - di_bk) ^ sdk ^ neg_i);
+  const float qj = rt_from_bits(rt_bits(dk_bj - dj_bk) ^ sdk ^ neg_j);
+  return (bpp > 0.f) & ((double)bpp < tdk) & (qi >= 0.f) & (qi <= side_adk) & (qj >= 0.f) & (qj <= side_adk);
+}
+
+// Node acceptance, same decision as rt_node_accept_literal for a cube with ini = (lo.x, lo.y, hi.z),
+// end = (hi.x, hi.y, lo.z) and power-of-two side.
+RT_HD bool rt_node_accept_exact(const RtVec3& ini, const RtVec3& end, const RtVec3& e, const RtVec3& d, const RtRayConst& rc,
+                                const RtTConst& tc) {
+  const float side = end.x - ini.x;
+  const float bxi = e.x - ini.x, bxe = e.x - end.x, byi = e.y - ini.y, bye = e.y - end.y, bzi = e.z - ini.z, bze = e.z - end.z;
+  const float sx = side * rc.ad[0], sy = side * rc.ad[1], sz = side * rc.ad[2];
+  const unsigned NEG = 0x80000000u;
+  const float dz_bxe = d.z * bxe, dz_bxi = d.z * bxi, dz_byi = d.z * byi, dz_bye = d.z * bye;
+  const float dx_bzi = d.x * bzi, dx_bze = d.x * bze, dx_byi = d.x * byi, dx_bye = d.x * bye;
+  const float dy_bzi = d.y * bzi, dy_bze = d.y * bze, dy_bxi = d.y * bxi, dy_bxe = d.y * bxe;
+  bool acc;
+  acc  = rt_face_exact(dz_bxe, dx_bzi, dz_byi, dy_bzi, bzi, rc.sd[2], NEG, 0u, sz, tc.td[2]);   // z = ini.z, from (end.x, ini.y)
+  acc |= rt_face_exact(dx_bzi, dz_bxi, dx_byi, dy_bxi, bxi, rc.sd[0], NEG, 0u, sx, tc.td[0]);   // x = ini.x, from (ini.y, ini.z)
+  acc |= rt_face_exact(dz_bxi, dx_bze, dz_byi, dy_bze, bze, rc.sd[2], 0u, 0u, sz, tc.td[2]);    // z = end.z, from (ini.x, ini.y)
+  acc |= rt_face_exact(dx_bze, dz_bxe, dx_byi, dy_bxe, bxe, rc.sd[0], 0u, 0u, sx, tc.td[0]);    // x = end.x, from (ini.y, end.z)
+  acc |= rt_face_exact(dy_bxi, dx_bye, dy_bze, dz_bye, bye, rc.sd[1], 0u, 0u, sy, tc.td[1]);    // y = end.y, from (ini.x, end.z)
+  acc |= rt_face_exact(dy_bxi, dx_byi, dy_bzi, dz_byi, byi, rc.sd[1], 0u, NEG, sy, tc.td[1]);   // y = ini.y, from (ini.x, ini.z)
+  return acc;
+}
+
+// Triangle numerators and determinant with the reference's rounding (triangle.cu:117-133, before the divisions).
+struct RtTriNum { float det, nb, ng, nt; };
+
+RT_HD RtTriNum rt_triangle_numerators(const RtVec3& v0, const RtVec3& e1, const RtVec3& e2, const RtVec3& eye, const RtVec3& dir) {
+  const RtVec3 b = {eye.x - v0.x, eye.y - v0.y, eye.z - v0.z};
+  const RtVec3 c2 = {-dir.x, -dir.y, -dir.z};
+  const float m00 = e2.y * c2.z - c2.y * e2.z;
+  const float m10 = -e2.x * c2.z + e2.z * c2.x;
+  const float m20 = e2.x * c2.y - e2.y * c2.x;
+  RtTriNum n;
+  n.det = e1.x * m00 + e1.y * m10 + e1.z * m20;
+  n.nb = m00 * b.x + m10 * b.y + m20 * b.z;
+  const float m01 = -e1.y * c2.z + e1.z * c2.y;
+  const float m11 = e1.x * c2.z - e1.z * c2.x;
+  const float m21 = -e1.x * c2.y + e1.y * c2.x;
+  n.ng = m01 * b.x + m11 * b.y + m21 * b.z;
+  const float m02 = e1.y * e2.z - e1.z * e2.y;
+  const float m12 = -e1.x * e2.z + e1.z * e2.x;
+  const float m22 = e1.x * e2.y - e1.y * e2.x;
+  n.nt = m02 * b.x + m12 * b.y + m22 * b.z;
+  return n;
+}
+
+// Everything of the triangle accept rule that needs no division: 0 <= beta <= 1, 0 <= gamma <= 1, 0 < t.
+RT_HD bool rt_triangle_candidate(const RtTriNum& n) {
+  const unsigned s = rt_bits(n.det) & 0x80000000u;
+  const float ad = fabsf(n.det);
+  const float nb = rt_from_bits(rt_bits(n.nb) ^ s), ng = rt_from_bits(rt_bits(n.ng) ^ s), nt = rt_from_bits(rt_bits(n.nt) ^ s);
+  return (ad > 0.f) & (nb >= 0.f) & (nb <= ad) & (ng >= 0.f) & (ng <= ad) & (nt > 0.f);
+}
+
+// Final decision for a candidate, with the reference's quotients (triangle.cu:131-137).
+RT_HD bool rt_triangle_finish(const RtTriNum& n, float t_max, float& t, float& bet, float& gam) {
+  const float x0 = n.nb / n.det, x1 = n.ng / n.det, x2 = n.nt / n.det;
+  const float alp = 1 - x0 - x1;
+  if (0 < x2 && x2 < t_max && 0 <= x0 && x0 <= 1 && 0 <= x1 && x1 <= 1 && 0 <= alp) { t = x2; bet = x0; gam = x1; return true; }
+  return false;
+}
+
 #endif

@@ -34,10 +34,17 @@ def _check_scene(name, w, h, depth=3):
         if name == "meshTransparentBunny" and k != "rays" and k != "shadow_rays":
             continue   # refraction directions differ by ulps between device and glibc powf/pow: counts may drift
         assert st[k] == oct_[k], (name, k, st[k], oct_[k])
-    # production variant (shadow rays stop at the first occluder): same image, same ray count
+    # production variant (shadow rays stop at the first occluder, one shadow ray per hit point and light):
+    # same image, same count of reference rays, fewer traversals
     rgb2, ids2, ts2, st2 = ds.render_host()
     assert np.array_equal(rgb2, rgb) and np.array_equal(ids2, ids) and np.array_equal(ts2.view(np.uint32), ts.view(np.uint32))
     assert st2["rays"] == st["rays"] and st2["shadow_rays"] == st["shadow_rays"]
+    assert st2["rays_traced"] <= st["rays_traced"] == st["rays"]
+    # cross-check kernel (one stack per pixel, the reference's solves evaluated as written): identical output
+    rgb3, ids3, ts3, st3 = ds.render_host(flags=rt.RT_RENDER_LITERAL | rt.RT_RENDER_COUNT_TESTS)
+    assert np.array_equal(rgb3, rgb) and np.array_equal(ids3, ids) and np.array_equal(ts3.view(np.uint32), ts.view(np.uint32))
+    for k in COUNTER_KEYS:
+        assert st3[k] == st[k], (name, k)
     return frac_ok, n_diff, max_diff
 
 
