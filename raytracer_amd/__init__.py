@@ -16,7 +16,8 @@ import numpy as np
 _HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(_HERE)
 ASSETS = os.path.join(ROOT, "assets")
-LIB_PATH = os.path.join(_HERE, "librt_amd.so")
+# RT_AMD_LIB selects another build of the same library (kernel tuning experiments).
+LIB_PATH = os.environ.get("RT_AMD_LIB") or os.path.join(_HERE, "librt_amd.so")
 
 RT_RENDER_COUNT_TESTS = 1
 RT_RENDER_TIME = 2

@@ -57,7 +57,7 @@ extern "C" int rt_scene_upload(const rt_scene* s, int device, rt_dscene** out) {
   if (hipGetDeviceCount(&n_dev) != hipSuccess || n_dev < 1) { rt_set_error("no HIP device is visible; the render path has no CPU fallback"); return RT_ERR_DEVICE; }
   if (device < 0 || device >= n_dev) { rt_set_error("device index out of range"); return RT_ERR_ARG; }
   HIP_TRY(hipSetDevice(device));
-  static_assert(sizeof(RtNode) == 32 && sizeof(RtTriGeom) == 48 && sizeof(RtTriShade) == 64, "record sizes");
+  static_assert(sizeof(RtNode) == 32 && sizeof(RtTriGeom) == 48 && sizeof(RtTriShade) == 64 && sizeof(RtTriLeaf) == 64, "record sizes");
   rt_dscene* d = new rt_dscene();
   d->device = device; d->info = s->info;
   RtDeviceView& V = d->view; memset(&V, 0, sizeof V);

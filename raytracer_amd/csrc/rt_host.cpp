@@ -626,14 +626,21 @@ void load_scene_into(rt_scene& sc, const std::string& scene_path, const std::str
     TreeBuilder tb(sc); tb.build();
     // Leaf-ordered copy of the intersection records: a leaf's triangles are one contiguous run, so the
     // traversal streams them without the index indirection.
-    sc.tri_leaf.resize(sc.leaf_refs.size());
-    for (size_t r = 0; r < sc.leaf_refs.size(); r++) { sc.tri_leaf[r] = sc.tri_geom[sc.leaf_refs[r]]; sc.tri_leaf[r].mesh = sc.leaf_refs[r]; }
+    // One extra record at the end of both arrays, so that the traversal may always prefetch "the next one".
+    sc.tri_leaf.assign(sc.leaf_refs.size() + 1, RtTriLeaf{});
+    for (size_t r = 0; r < sc.leaf_refs.size(); r++) {
+      const RtTriGeom& g = sc.tri_geom[sc.leaf_refs[r]];
+      RtTriLeaf& t = sc.tri_leaf[r];
+      for (int k = 0; k < 3; k++) { t.v0[k] = g.v0[k]; t.e1[k] = g.e1[k]; t.e2[k] = g.e2[k]; }
+      t.id = sc.leaf_refs[r];
+    }
+    sc.nodes.push_back(RtNode{});   // pad; not counted in info.n_nodes
   }
   I.build_seconds = seconds_since(t_build);
   I.width = W; I.height = H; I.max_depth = depth;
   I.n_triangles = (int32_t)sc.tri_geom.size(); I.n_spheres = (int32_t)sc.spheres.size();
   I.n_lights = (int32_t)sc.lights.size(); I.n_materials = (int32_t)sc.materials.size();
-  I.n_nodes = (int32_t)sc.nodes.size(); I.shadows_enabled = c.shadows;
+  I.n_nodes = sc.nodes.empty() ? 0 : (int32_t)sc.nodes.size() - 1; I.shadows_enabled = c.shadows;
   if (!sc.nodes.empty()) tree_summary(sc, 0, 0, I);
   for (int32_t mi : sc.mat_index) if (sc.materials[mi].type == RT_REFLECTIVE || sc.materials[mi].type == RT_DIELECTRIC) I.has_bounce_materials = 1;
 }

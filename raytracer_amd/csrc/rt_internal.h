@@ -56,6 +56,9 @@ struct RtNode { float a[4]; float b[4]; };
 //   six operations of triangle.cu:118-120), then mesh index and two pads.
 struct RtTriGeom { float v0[3]; float e1[3]; float e2[3]; int32_t mesh; int32_t pad[2]; };
 
+// Leaf-ordered copy of the intersection record, 64 B = one 16-dword scalar load: v0, e1, e2, triangle id, pad.
+struct alignas(64) RtTriLeaf { float v0[3]; float e1[3]; float e2[3]; int32_t id; int32_t pad[6]; };
+
 // Triangle shading record, 64 B, read once per closest hit: v1, v2 and the three vertex normals.
 struct RtTriShade { float v1[3]; float v2[3]; float n0[3]; float n1[3]; float n2[3]; float pad; };
 
@@ -69,7 +72,7 @@ struct rt_scene {
   std::vector<RtNode> nodes;                      // nodes[0] = root (always a branch) when non-empty
   std::vector<int32_t> leaf_refs;
   std::vector<RtTriGeom> tri_geom;
-  std::vector<RtTriGeom> tri_leaf;                // tri_geom records repeated in leaf order (index space of leaf_refs); `mesh` holds the triangle id
+  std::vector<RtTriLeaf> tri_leaf;                // intersection records repeated in leaf order (index space of leaf_refs), plus one pad record
   std::vector<RtTriShade> tri_shade;
   std::vector<float> tri_verts, tri_normals;      // n*9 each, as the reference uploads them
   rt_scene_info info;

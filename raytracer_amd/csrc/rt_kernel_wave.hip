@@ -45,14 +45,19 @@ __device__ __forceinline__ void trace_wave(const float4* __restrict__ nodes, con
   const uint64_t lane_bit = 1ull << lane;
   uint64_t live = __ballot(want);
   if (!live) return;
-  const RtRayConst rc = rt_ray_const(d);
-  RtTConst tc = rt_t_const(rc, hit.t);
+  RtTFloat tf = rt_t_float(rt_ray_const(d), hit.t);
+  const RtVec3 inv = {1.f / d.x, 1.f / d.y, 1.f / d.z};   // only feeds the conservative classification
   bool mine_live = want;
 
   if (has_oct) {
     uint32_t top_first = uni(__float_as_uint(nodes[0].w)), top_cur = 0;   // the root is entered without a test (ray.cu:36-38)
     uint64_t top_mask = live;
     int sp = 0;
+    // Node records reach the SGPRs through the scalar cache.  The record of the next sibling is requested
+    // before the current one is evaluated, so its latency hides behind ~100 VALU instructions; only the
+    // first child after a descent or an ascent is waited for.  (Both arrays end with a pad record.)
+    uint32_t pre_idx = 0xffffffffu;
+    float4 pre_a = {0, 0, 0, 0}, pre_b = {0, 0, 0, 0};
     for (;;) {
       if (top_cur == 8u || (top_mask & live) == 0ull) {   // branch exhausted, or every lane that entered it is decided
         if (sp == 0) break;
@@ -63,10 +68,25 @@ __device__ __forceinline__ void trace_wave(const float4* __restrict__ nodes, con
       }
       const uint32_t child = top_first + top_cur;
       top_cur++;
-      const float4 na = nodes[2 * child], nb = nodes[2 * child + 1];
+      float4 na, nb;
+      if (child == pre_idx) { na = pre_a; nb = pre_b; }
+      else { na = nodes[2 * child]; nb = nodes[2 * child + 1]; }
+      pre_idx = child + 1u;
+      pre_a = nodes[2 * pre_idx]; pre_b = nodes[2 * pre_idx + 1];
       const bool mine = mine_live && (top_mask & lane_bit) != 0ull;
       if (COUNT && mine) tl.node++;
-      const bool acc = mine & rt_node_accept_exact({na.x, na.y, na.z}, {nb.x, nb.y, nb.z}, e, d, rc, tc);
+      const RtVec3 ini = {na.x, na.y, na.z}, end = {nb.x, nb.y, nb.z};
+      // conservative slab classification first; the exact test only where some lane is within rounding of a boundary
+      const int cls = rt_node_slab_class({na.x, na.y, nb.z}, {nb.x, nb.y, na.z}, e, inv, hit.t);
+      bool acc = mine & (cls > 0);
+      if (__ballot(mine & (cls == 0))) {
+        const float S = rt_node_score(ini, end, e, d, rt_ray_const(d), tf);
+        bool accS = S > 0.f;
+        if (__ballot(mine & (cls == 0) & (S == 0.f))) {   // a boundary case: settle it with the compare form
+          if (S == 0.f) accS = rt_node_accept_exact(ini, end, e, d, rt_ray_const(d), rt_t_const(rt_ray_const(d), hit.t));
+        }
+        if (cls == 0) acc = mine & accS;
+      }
       const uint64_t m = __ballot(acc);
       if (!m) continue;
       const uint32_t first = uni(__float_as_uint(na.w));
@@ -83,11 +103,16 @@ __device__ __forceinline__ void trace_wave(const float4* __restrict__ nodes, con
       }
       // leaf: every triangle in insertion order (octtree.cu:264-274); all lanes in `m` test the same triangle
       if (COUNT && acc) { tl.leaf++; tl.tri += (uint32_t)count; }
+      if (count == 0) continue;
       bool changed = false;
+      const float4* tp = tri_leaf + 4 * (size_t)first;
+      float4 g0 = tp[0], g1 = tp[1], g2 = tp[2];
       for (int32_t k = 0; k < count; k++) {
-        const uint32_t r = first + (uint32_t)k;
-        const float4 g0 = tri_leaf[3 * r], g1 = tri_leaf[3 * r + 1], g2 = tri_leaf[3 * r + 2];
+        tp += 4;
+        const float4 h0 = tp[0], h1 = tp[1], h2 = tp[2];   // next triangle of the leaf (or the pad record)
         const RtVec3 v0 = {g0.x, g0.y, g0.z}, e1 = {g0.w, g1.x, g1.y}, e2 = {g1.z, g1.w, g2.x};
+        const int32_t tri_id = (int32_t)__float_as_uint(g2.y);
+        g0 = h0; g1 = h1; g2 = h2;
         // stage 1: determinant and beta numerator (triangle.cu:117-131, first column of cofactors)
         const RtVec3 b = {e.x - v0.x, e.y - v0.y, e.z - v0.z};
         const RtVec3 c2 = {-d.x, -d.y, -d.z};
@@ -100,7 +125,8 @@ __device__ __forceinline__ void trace_wave(const float4* __restrict__ nodes, con
         const unsigned s = rt_bits(n.det) & 0x80000000u;
         const float ad = fabsf(n.det);
         const float nbs = rt_from_bits(rt_bits(n.nb) ^ s);
-        bool pass = acc & (ad > 0.f) & (nbs >= 0.f) & (nbs <= ad);
+        // 0 <= beta <= 1 with det != 0  <=>  min(nbs, ad - nbs) >= 0 and ad > 0
+        bool pass = acc & (ad > 0.f) & (fminf(nbs, ad - nbs) >= 0.f);
         if (!__ballot(pass)) continue;
         // stage 2: gamma numerator
         const float m01 = -e1.y * c2.z + e1.z * c2.y;
@@ -108,7 +134,7 @@ __device__ __forceinline__ void trace_wave(const float4* __restrict__ nodes, con
         const float m21 = -e1.x * c2.y + e1.y * c2.x;
         n.ng = m01 * b.x + m11 * b.y + m21 * b.z;
         const float ngs = rt_from_bits(rt_bits(n.ng) ^ s);
-        pass = pass & (ngs >= 0.f) & (ngs <= ad);
+        pass = pass & (fminf(ngs, ad - ngs) >= 0.f);
         if (!__ballot(pass)) continue;
         // stage 3: t numerator; t > 0, and t clearly beyond the closest hit is rejected without dividing
         const float m02 = e1.y * e2.z - e1.z * e2.y;
@@ -121,14 +147,14 @@ __device__ __forceinline__ void trace_wave(const float4* __restrict__ nodes, con
         if (pass) {   // the reference's quotients decide (triangle.cu:131-137)
           float t, bet, gam;
           if (rt_triangle_finish(n, hit.t, t, bet, gam)) {
-            hit.t = t; hit.prim = (int32_t)__float_as_uint(g2.y); hit.bet = bet; hit.gam = gam;
+            hit.t = t; hit.prim = tri_id; hit.bet = bet; hit.gam = gam;
             changed = true;
           }
         }
       }
       if (__ballot(changed)) {
         if (changed) {
-          tc = rt_t_const(rc, hit.t);
+          tf = rt_t_float(rt_ray_const(d), hit.t);
           if (stop_t >= 0.f && hit.t < stop_t) mine_live = false;
         }
         live = __ballot(mine_live);
@@ -149,14 +175,57 @@ __device__ __forceinline__ void trace_wave(const float4* __restrict__ nodes, con
 
 enum { PH_CLOSEST = 0, PH_SHADOW = 1, PH_DONE = 2, PH_SHADE = 3 };
 
+#ifndef RT_WAVES_PER_SIMD
+#define RT_WAVES_PER_SIMD 5
+#endif
+
+// Shading state of a lane.  It is dead while the wave traverses the octree, and the traversal is where
+// the registers are needed, so it is parked in LDS ([word][thread], conflict-free) around every trace.
+template <bool BOUNCE>
+struct ShadeState {
+  RtVec3 P, N, view;                 // hit point, shading normal, direction of the ray being shaded
+  float colr[3], color[3];           // colour of the ray being shaded, colour of the pixel so far
+  float hit_t;                       // distance of the hit being shaded (Beer attenuation)
+  int32_t mfirst, mcount, mi, li;    // material list of the hit primitive, (material, light) cursor
+  uint32_t vis_known, vis_occluded;  // per light (first 32): shadow test already traced for this hit point
+  RtVec3 att; float level[RT_MAX_LEVELS]; int32_t nlevel, depth;   // BOUNCE only
+  static constexpr int WORDS = BOUNCE ? 30 : 22;
+};
+
+template <bool BOUNCE>
+__device__ __forceinline__ void park(const ShadeState<BOUNCE>& s, float* lds) {
+  const float w[30] = {s.P.x, s.P.y, s.P.z, s.N.x, s.N.y, s.N.z, s.view.x, s.view.y, s.view.z, s.colr[0], s.colr[1], s.colr[2],
+                       s.color[0], s.color[1], s.color[2], s.hit_t, __int_as_float(s.mfirst), __int_as_float(s.mcount),
+                       __int_as_float(s.mi), __int_as_float(s.li), __uint_as_float(s.vis_known), __uint_as_float(s.vis_occluded),
+                       s.att.x, s.att.y, s.att.z, s.level[0], s.level[1], s.level[2], __int_as_float(s.nlevel), __int_as_float(s.depth)};
+#pragma unroll
+  for (int k = 0; k < ShadeState<BOUNCE>::WORDS; k++) lds[k * RT_BLOCK] = w[k];
+}
+template <bool BOUNCE>
+__device__ __forceinline__ void unpark(ShadeState<BOUNCE>& s, const float* lds) {
+  float w[30];
+#pragma unroll
+  for (int k = 0; k < 30; k++) w[k] = k < ShadeState<BOUNCE>::WORDS ? lds[k * RT_BLOCK] : 0.f;
+  s.P = {w[0], w[1], w[2]}; s.N = {w[3], w[4], w[5]}; s.view = {w[6], w[7], w[8]};
+  s.colr[0] = w[9]; s.colr[1] = w[10]; s.colr[2] = w[11]; s.color[0] = w[12]; s.color[1] = w[13]; s.color[2] = w[14];
+  s.hit_t = w[15]; s.mfirst = __float_as_int(w[16]); s.mcount = __float_as_int(w[17]); s.mi = __float_as_int(w[18]);
+  s.li = __float_as_int(w[19]); s.vis_known = __float_as_uint(w[20]); s.vis_occluded = __float_as_uint(w[21]);
+  if (BOUNCE) {
+    s.att = {w[22], w[23], w[24]}; s.level[0] = w[25]; s.level[1] = w[26]; s.level[2] = w[27];
+    s.nlevel = __float_as_int(w[28]); s.depth = __float_as_int(w[29]);
+  }
+}
+
 template <bool BOUNCE, bool COUNT>
-__global__ __launch_bounds__(RT_BLOCK) void render_wave(
+__global__ __launch_bounds__(RT_BLOCK, RT_WAVES_PER_SIMD) void render_wave(
     const RtCamera cam, const RowMap rows, const float4* __restrict__ nodes, const float4* __restrict__ tri_leaf,
     const float4* __restrict__ tri_geom, const float4* __restrict__ tri_shade, const RtSphere* __restrict__ spheres,
     const RtLight* __restrict__ lights, const RtMaterial* __restrict__ materials, const int32_t* __restrict__ mat_index,
     const int32_t* __restrict__ mesh_mat_first, const int32_t* __restrict__ mesh_mat_count, int n_spheres, int n_lights, int has_oct,
     uint8_t* __restrict__ rgb, int32_t* __restrict__ ids, float* __restrict__ ts, unsigned long long* __restrict__ counters) {
+  __shared__ float parked[ShadeState<BOUNCE>::WORDS * RT_BLOCK];
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  float* my_park = &parked[tid];
   WaveStack st = {0u, 0u, 0u, 0u};
   const int W = cam.width, H = cam.height;
   const int col = blockIdx.x * RT_TILE_W + (wave & 1) * 8 + (lane & 7);
@@ -171,85 +240,94 @@ __global__ __launch_bounds__(RT_BLOCK) void render_wave(
   RtDeviceView S;
   S.tri_geom = tri_geom; S.tri_shade = tri_shade; S.spheres = spheres;
 
-  // ---- per-lane path state -------------------------------------------------------------------
-  BounceRay cur;   // ray being shaded (or traced, in PH_CLOSEST)
+  // ---- registers that live across the traversal: the ray being traced and a few flags -----------------
+  RtVec3 tr_e, tr_d;        // ray being traced
+  float tr_stop = -1.f;     // >= 0: shadow ray, length to the light
   {
     const int i = col, j = H - 1 - row;   // camera.cu:94,118: j counts from the bottom
     // camera.cu:96-99; (i+0.5) is a double, so product and sum are double before the store to float
     const float ic = (float)((double)c.left + (double)((c.right - c.left) / (float)(unsigned short)W) * ((double)i + 0.5));
     const float jc = (float)((double)c.bottom + (double)((c.top - c.bottom) / (float)(unsigned short)H) * ((double)j + 0.5));
     const float kz = -RT_NEAR;
-    RtVec3 d0 = {ic * c.u[0] + jc * c.v[0] + kz * c.w[0], ic * c.u[1] + jc * c.v[1] + kz * c.w[1], ic * c.u[2] + jc * c.v[2] + kz * c.w[2]};
-    cur.dir = rt_normalized(d0);
-    cur.eye = {c.pos[0], c.pos[1], c.pos[2]}; cur.att = {1.f, 1.f, 1.f};
-    cur.level[0] = c.scene_refr; cur.level[1] = 0.f; cur.level[2] = 0.f; cur.nlevel = 0; cur.depth = 0;
+    const RtVec3 d0 = {ic * c.u[0] + jc * c.v[0] + kz * c.w[0], ic * c.u[1] + jc * c.v[1] + kz * c.w[1], ic * c.u[2] + jc * c.v[2] + kz * c.w[2]};
+    tr_d = rt_normalized(d0);
+    tr_e = {c.pos[0], c.pos[1], c.pos[2]};
   }
-  BounceRay rstack[BOUNCE ? RT_RAY_STACK : 1];
-  int rsp = 0;
   int phase = valid ? PH_CLOSEST : PH_DONE;
   bool primary = true;
-  float color[3] = {0.f, 0.f, 0.f}, colr[3] = {0.f, 0.f, 0.f};
-  Hit hit = {RT_INF, -1, 0.f, 0.f};        // closest hit of `cur`
-  RtVec3 P = {0, 0, 0}, N = {0, 0, 1};
-  int32_t mfirst = 0, mcount = 0, mi = 0, li = 0;
-  uint32_t vis_known = 0, vis_occluded = 0;   // per light (first 32): shadow test already traced for this hit point
-  RtVec3 sray_e = {0, 0, 0}, sray_d = {0, 0, 1}; float sray_len = 0.f;   // pending shadow ray
-  int verdict = -1;                                                        // result of the last shadow ray, until consumed
+  int verdict = -1;   // result of the last shadow ray, until consumed
+
+  // ---- shading state (parked during traversal) and the pixel's ray stack (scratch, BOUNCE only) --------
+  ShadeState<BOUNCE> sh;
+  sh.P = {0, 0, 0}; sh.N = {0, 0, 1}; sh.view = tr_d;
+  for (int k = 0; k < 3; k++) { sh.colr[k] = 0.f; sh.color[k] = 0.f; sh.level[k] = 0.f; }
+  sh.hit_t = RT_INF; sh.mfirst = 0; sh.mcount = 0; sh.mi = 0; sh.li = 0; sh.vis_known = 0; sh.vis_occluded = 0;
+  sh.att = {1.f, 1.f, 1.f}; sh.level[0] = c.scene_refr; sh.nlevel = 0; sh.depth = 0;
+  BounceRay rstack[BOUNCE ? RT_RAY_STACK : 1];
+  int rsp = 0;
 
   while (__ballot(phase != PH_DONE)) {
-    // ---- trace the pending rays of the wave ---------------------------------------------------
+    // ---- trace the pending rays of the wave ---------------------------------------------------------
+    Hit h = {RT_INF, -1, 0.f, 0.f};
     {
       const bool want = phase != PH_DONE;
-      const bool is_shadow = phase == PH_SHADOW;
-      Hit h = {RT_INF, -1, 0.f, 0.f};
-      const RtVec3 te = is_shadow ? sray_e : cur.eye, td = is_shadow ? sray_d : cur.dir;
       // the instrumented variant walks shadow rays to the end, as the reference does, so that its test counts match
-      const float stop_t = (is_shadow && !COUNT) ? sray_len : -1.f;
+      const float stop_t = (phase == PH_SHADOW && !COUNT) ? tr_stop : -1.f;
       if (want) tl.traced++;
-      trace_wave<COUNT>(nodes, tri_leaf, spheres, n_spheres, has_oct != 0, want, te, td, stop_t, h, st, lane, tl);
-      if (phase == PH_CLOSEST) {
-        hit = h;
-        if (primary) {
-          primary = false;
-          const size_t p = (size_t)orow * W + col;
-          if (ids) ids[p] = hit.prim;
-          if (ts) ts[p] = hit.t;
-        }
-        colr[0] = colr[1] = colr[2] = 0.f;
-        mi = 0; li = 0; vis_known = 0; vis_occluded = 0;
-        if (hit.prim == -1) {
-          colr[0] = c.bg[0]; colr[1] = c.bg[1]; colr[2] = c.bg[2];   // ray.cu:86
-          mcount = 0;
-        } else {
-          surface(S, cur.eye, cur.dir, hit, P, N);
-          if (hit.prim >= 0) {
-            const int32_t mesh = (int32_t)__float_as_uint(tri_geom[3 * hit.prim + 2].y);
-            mfirst = mesh_mat_first[mesh]; mcount = mesh_mat_count[mesh];
-          } else { mfirst = spheres[-2 - hit.prim].mat_first; mcount = spheres[-2 - hit.prim].mat_count; }
-        }
-      } else if (phase == PH_SHADOW) {
-        verdict = sray_len > h.t ? 1 : 0;   // ray.cu:70; consumed by the (material, light) step that asked for it
-      }
+      park<BOUNCE>(sh, my_park);
+      asm volatile("" ::: "memory");
+      trace_wave<COUNT>(nodes, tri_leaf, spheres, n_spheres, has_oct != 0, want, tr_e, tr_d, stop_t, h, st, lane, tl);
+      asm volatile("" ::: "memory");
+      unpark<BOUNCE>(sh, my_park);
     }
-    // ---- shade until the lane needs another ray or its pixel is finished ------------------------
+    if (phase == PH_CLOSEST) {
+      if (primary) {
+        primary = false;
+        const size_t p = (size_t)orow * W + col;
+        if (ids) ids[p] = h.prim;
+        if (ts) ts[p] = h.t;
+      }
+      sh.colr[0] = sh.colr[1] = sh.colr[2] = 0.f;
+      sh.mi = 0; sh.li = 0; sh.vis_known = 0; sh.vis_occluded = 0; sh.hit_t = h.t; sh.view = tr_d;
+      if (h.prim == -1) {
+        sh.colr[0] = c.bg[0]; sh.colr[1] = c.bg[1]; sh.colr[2] = c.bg[2];   // ray.cu:86
+        sh.mcount = 0;
+      } else {
+        surface(S, tr_e, tr_d, h, sh.P, sh.N);
+        if (h.prim >= 0) {
+          const int32_t mesh = (int32_t)__float_as_uint(tri_geom[3 * h.prim + 2].y);
+          sh.mfirst = mesh_mat_first[mesh]; sh.mcount = mesh_mat_count[mesh];
+        } else { sh.mfirst = spheres[-2 - h.prim].mat_first; sh.mcount = spheres[-2 - h.prim].mat_count; }
+      }
+    } else if (phase == PH_SHADOW) {
+      verdict = tr_stop > h.t ? 1 : 0;   // ray.cu:70; consumed by the (material, light) step that asked for it
+    }
+    // ---- shade until the lane needs another ray or its pixel is finished --------------------------------
     if (phase != PH_DONE) {
       phase = PH_SHADE;
       while (phase == PH_SHADE) {
-        if (mi >= mcount) {   // every material of the hit handled: camera.cu:110-111, then next ray of the pixel
-          color[0] = color[0] + cur.att.x * colr[0];
-          color[1] = color[1] + cur.att.y * colr[1];
-          color[2] = color[2] + cur.att.z * colr[2];
-          if (BOUNCE && rsp > 0) { cur = rstack[--rsp]; phase = PH_CLOSEST; tl.rays++; }
-          else phase = PH_DONE;
+        if (sh.mi >= sh.mcount) {   // every material of the hit handled: camera.cu:110-111, then next ray of the pixel
+          sh.color[0] = sh.color[0] + sh.att.x * sh.colr[0];
+          sh.color[1] = sh.color[1] + sh.att.y * sh.colr[1];
+          sh.color[2] = sh.color[2] + sh.att.z * sh.colr[2];
+          if (BOUNCE && rsp > 0) {
+            const BounceRay& r = rstack[--rsp];
+            tr_e = r.eye; tr_d = r.dir; sh.att = r.att;
+            for (int k = 0; k < 3; k++) sh.level[k] = r.level[k];
+            sh.nlevel = r.nlevel; sh.depth = r.depth;
+            phase = PH_CLOSEST; tl.rays++;
+          } else phase = PH_DONE;
           break;
         }
-        const RtMaterial M = materials[mat_index[mfirst + mi]];
+        const RtMaterial M = materials[mat_index[sh.mfirst + sh.mi]];
+        const RtVec3 P = sh.P, N = sh.N;
         if (M.type == RT_LAMBERT || M.type == RT_PHONG) {   // material.cu:15-24, lights.cu:260-367
-          if (li >= n_lights) { mi++; li = 0; continue; }
+          const int li = sh.li;
+          if (li >= n_lights) { sh.mi++; sh.li = 0; continue; }
           const RtLight L = lights[li];
           if (L.type == RT_AMBIENT) {
-            if (M.type == RT_LAMBERT) for (int k = 0; k < 3; k++) colr[k] = colr[k] + M.col[k] * L.col[k];
-            li++; continue;
+            if (M.type == RT_LAMBERT) for (int k = 0; k < 3; k++) sh.colr[k] = sh.colr[k] + M.col[k] * L.col[k];
+            sh.li++; continue;
           }
           RtVec3 l; float ldist;
           if (L.type == RT_DIRECTIONAL) { l = {L.dir[0] * -1, L.dir[1] * -1, L.dir[2] * -1}; ldist = RT_INF; }
@@ -260,89 +338,90 @@ __global__ __launch_bounds__(RT_BLOCK) void render_wave(
             bool occluded;
             if (verdict >= 0) {   // the trace requested by this very step has come back
               occluded = verdict != 0; verdict = -1;
-              if (!COUNT && li < 32) { vis_known |= 1u << li; if (occluded) vis_occluded |= 1u << li; }
-            } else if (!COUNT && li < 32 && ((vis_known >> li) & 1u)) {
+              if (!COUNT && li < 32) { sh.vis_known |= 1u << li; if (occluded) sh.vis_occluded |= 1u << li; }
+            } else if (!COUNT && li < 32 && ((sh.vis_known >> li) & 1u)) {
               // origin, direction and length depend on the hit point and the light only, so every further
               // material of this hit gets the verdict of the ray already traced (the instrumented variant
               // re-traces, to count what the reference does)
-              occluded = (vis_occluded >> li) & 1u;
+              occluded = (sh.vis_occluded >> li) & 1u;
             } else {
-              sray_e = sP; sray_d = l; sray_len = ldist; phase = PH_SHADOW;
+              tr_e = sP; tr_d = l; tr_stop = ldist; phase = PH_SHADOW;
               break;
             }
             tl.rays++; tl.shadow++;   // the reference casts this ray for every (material, light) pair
-            if (occluded) { li++; continue; }
+            if (occluded) { sh.li++; continue; }
           }
-          if (L.type == RT_SPOT && !(-rt_dot(l, ld3(L.dir)) > L.cos_half)) { li++; continue; }
+          if (L.type == RT_SPOT && !(-rt_dot(l, ld3(L.dir)) > L.cos_half)) { sh.li++; continue; }
           float w;
           if (M.type == RT_LAMBERT) { const float nl = rt_dot(N, l); w = nl > 0.f ? nl : 0.f; }
           else {
-            const RtVec3 h = rt_normalized({cur.dir.x * -1 + l.x, cur.dir.y * -1 + l.y, cur.dir.z * -1 + l.z});
-            const float nh = rt_dot(N, h);
+            const RtVec3 hv = rt_normalized({sh.view.x * -1 + l.x, sh.view.y * -1 + l.y, sh.view.z * -1 + l.z});
+            const float nh = rt_dot(N, hv);
             w = powf(nh > 0.f ? nh : 0.f, M.param);
           }
-          for (int k = 0; k < 3; k++) colr[k] = colr[k] + (M.col[k] * L.col[k]) * w;
-          li++;
+          for (int k = 0; k < 3; k++) sh.colr[k] = sh.colr[k] + (M.col[k] * L.col[k]) * w;
+          sh.li++;
         } else {
-          if (BOUNCE && cur.depth < c.max_depth) {
-            const float s2 = 2 * rt_dot(cur.dir, N);
-            const RtVec3 rl = rt_normalized({cur.dir.x - N.x * s2, cur.dir.y - N.y * s2, cur.dir.z - N.z * s2});
+          if (BOUNCE && sh.depth < c.max_depth) {
+            const RtVec3 vd = sh.view;
+            const float s2 = 2 * rt_dot(vd, N);
+            const RtVec3 rl = rt_normalized({vd.x - N.x * s2, vd.y - N.y * s2, vd.z - N.z * s2});
             if (M.type == RT_REFLECTIVE) {   // material.cu:25-35
               if (rsp < RT_RAY_STACK) {
                 BounceRay& r = rstack[rsp++];
                 r.eye = {P.x + rl.x * RT_EPS, P.y + rl.y * RT_EPS, P.z + rl.z * RT_EPS}; r.dir = rl;
-                r.att = {M.col[0] * cur.att.x, M.col[1] * cur.att.y, M.col[2] * cur.att.z};
-                for (int k = 0; k < 3; k++) r.level[k] = cur.level[k];
-                r.nlevel = cur.nlevel; r.depth = cur.depth + 1;
+                r.att = {M.col[0] * sh.att.x, M.col[1] * sh.att.y, M.col[2] * sh.att.z};
+                for (int k = 0; k < 3; k++) r.level[k] = sh.level[k];
+                r.nlevel = sh.nlevel; r.depth = sh.depth + 1;
               } else atomicAdd(&counters[C_UB_STACK], 1ull);
             } else {   // RT_DIELECTRIC, material.cu:36-99
-              const float refr = cur.level[cur.nlevel];
+              const float refr = sh.level[sh.nlevel];
               const RtVec3 rlsP = {P.x + N.x * RT_EPS, P.y + N.y * RT_EPS, P.z + N.z * RT_EPS};
               const float q = (refr - M.param) / (refr + M.param);
               const float R0 = q * q;
-              const float dn = rt_dot(cur.dir, N);
+              const float dn = rt_dot(vd, N);
               const bool entering = dn < 0;
               float rOrI, cs; RtVec3 nn; float K[3];
               if (entering) { rOrI = refr / M.param; cs = -dn; nn = N; K[0] = K[1] = K[2] = 1.0f; }
               else {
                 rOrI = M.param / refr; cs = dn; nn = {N.x * -1, N.y * -1, N.z * -1};
-                for (int k = 0; k < 3; k++) K[k] = expf(M.att[k] * -hit.t);
+                for (int k = 0; k < 3; k++) K[k] = expf(M.att[k] * -sh.hit_t);
               }
               const float totRefl = 1 - (rOrI * rOrI) * (1 - cs * cs);
-              const float a3[3] = {cur.att.x, cur.att.y, cur.att.z};
+              const float a3[3] = {sh.att.x, sh.att.y, sh.att.z};
               float attl[3], attf[3];
               for (int k = 0; k < 3; k++) { attl[k] = (M.col[k] * K[k]) * a3[k]; attf[k] = attl[k]; }
               if (totRefl >= 0) {
-                const RtVec3 rf = refract_dir(cur.dir, nn, rOrI);
+                const RtVec3 rf = refract_dir(vd, nn, rOrI);
                 const float fresnel = (float)((double)R0 + (double)(1 - R0) * pow(1.0 - (double)cs, 5.0));
                 for (int k = 0; k < 3; k++) attf[k] = attf[k] * (1 - fresnel);
                 int nl;
                 if (entering) {
-                  nl = cur.nlevel + 1;
+                  nl = sh.nlevel + 1;
                   if (nl > 2) { nl = 2; atomicAdd(&counters[C_UB_OVER], 1ull); }
-                  cur.level[nl] = M.param;
+                  sh.level[nl] = M.param;
                 } else {
-                  nl = cur.nlevel - 1;
+                  nl = sh.nlevel - 1;
                   if (nl < 0) { nl = 0; atomicAdd(&counters[C_UB_LEAVE], 1ull); }
                 }
                 if (rsp < RT_RAY_STACK) {
                   BounceRay& r = rstack[rsp++];
                   r.eye = {P.x + rf.x * RT_EPS, P.y + rf.y * RT_EPS, P.z + rf.z * RT_EPS}; r.dir = rf;
                   r.att = {attf[0], attf[1], attf[2]};
-                  for (int k = 0; k < 3; k++) r.level[k] = cur.level[k];
-                  r.nlevel = nl; r.depth = cur.depth + 1;
+                  for (int k = 0; k < 3; k++) r.level[k] = sh.level[k];
+                  r.nlevel = nl; r.depth = sh.depth + 1;
                 } else atomicAdd(&counters[C_UB_STACK], 1ull);
                 for (int k = 0; k < 3; k++) attl[k] = attl[k] * fresnel;
               }
               if (rsp < RT_RAY_STACK) {
                 BounceRay& r = rstack[rsp++];
                 r.eye = rlsP; r.dir = rl; r.att = {attl[0], attl[1], attl[2]};
-                for (int k = 0; k < 3; k++) r.level[k] = cur.level[k];
-                r.nlevel = cur.nlevel; r.depth = cur.depth + 1;
+                for (int k = 0; k < 3; k++) r.level[k] = sh.level[k];
+                r.nlevel = sh.nlevel; r.depth = sh.depth + 1;
               } else atomicAdd(&counters[C_UB_STACK], 1ull);
             }
           }
-          mi++; li = 0;
+          sh.mi++; sh.li = 0;
         }
       }
     }
@@ -351,7 +430,7 @@ __global__ __launch_bounds__(RT_BLOCK) void render_wave(
   if (valid) {
     const size_t p = ((size_t)orow * W + col) * 3;
     for (int k = 0; k < 3; k++) {   // camera.cu:113-122; NaN < 1 is false, so NaN -> 1 -> 255
-      const float v = (color[k] < 1.f ? color[k] : 1.f) * 255.f;
+      const float v = (sh.color[k] < 1.f ? sh.color[k] : 1.f) * 255.f;
       rgb[p + k] = v < 0.f ? (uint8_t)0 : (uint8_t)(int)v;
     }
     tl.rays++;   // the primary ray

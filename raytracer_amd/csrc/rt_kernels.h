@@ -17,7 +17,7 @@ struct RtDeviceView {
   const float4* nodes;        // 2 per node
   const int32_t* leaf_refs;
   const float4* tri_geom;     // 3 per triangle, indexed by triangle id
-  const float4* tri_leaf;     // 3 per leaf reference, in leaf order (same index space as leaf_refs)
+  const float4* tri_leaf;     // 4 per leaf reference (RtTriLeaf), in leaf order (same index space as leaf_refs)
   const float4* tri_shade;    // 4 per triangle
   const RtSphere* spheres;
   const RtLight* lights;

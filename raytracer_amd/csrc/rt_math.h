@@ -221,4 +221,110 @@ RT_HD bool rt_triangle_finish(const RtTriNum& n, float t_max, float& t, float& b
   return false;
 }
 
+
+// ------------------------------------------------------------------------------------------------
+// The same node decision as one number.  Every condition of a face is a sign condition on a float:
+//   t > 0        <=> bpp > 0                 t < T   <=> tdf_k - bpp > 0   (tdf_k = smallest float >= Tm |d_k|)
+//   offset >= 0  <=> q >= 0                  offset <= side <=> side|d_k| - q >= 0
+// (the sign of a float difference is the sign of the exact difference).  score(face) = min of its six
+// terms, S = max over the faces:  S > 0 => some face satisfies everything strictly => accept;
+// S < 0 (or NaN) => every face violates something => reject;  S == 0 => a boundary case, to be settled
+// with rt_node_accept_exact.
+// ------------------------------------------------------------------------------------------------
+struct RtTFloat { float tdf[3]; };
+
+RT_HD float rt_round_up_to_float(double y) {   // smallest float >= y, for y >= 0 (NaN stays NaN)
+  float f = (float)y;
+  if ((double)f < y) f = rt_from_bits(rt_bits(f) + 1u);
+  return f;
+}
+RT_HD RtTFloat rt_t_float(const RtRayConst& r, float T) {
+  const RtTConst c = rt_t_const(r, T);
+  RtTFloat f;
+  f.tdf[0] = rt_round_up_to_float(c.td[0]); f.tdf[1] = rt_round_up_to_float(c.td[1]); f.tdf[2] = rt_round_up_to_float(c.td[2]);
+  return f;
+}
+RT_HD float rt_min3(float a, float b, float c) { return fminf(fminf(a, b), c); }
+RT_HD float rt_max3(float a, float b, float c) { return fmaxf(fmaxf(a, b), c); }
+
+RT_HD float rt_face_score(float dk_bi, float di_bk, float dk_bj, float dj_bk, float bk, unsigned sdk, unsigned neg_i,
+                          unsigned neg_j, float side_adk, float tdfk) {
+  const float bpp = rt_from_bits(rt_bits(bk) ^ sdk ^ 0x80000000u);
+  const float qi = rt_from_bits(rt_bits(dk_bi - di_bk) ^ sdk ^ neg_i);
+  const float qj = rt_from_bits(rt_bits(dk_bj - dj_bk) ^ sdk ^ neg_j);
+  return fminf(rt_min3(bpp, tdfk - bpp, qi), rt_min3(side_adk - qi, qj, side_adk - qj));
+}
+
+RT_HD float rt_node_score(const RtVec3& ini, const RtVec3& end, const RtVec3& e, const RtVec3& d, const RtRayConst& rc,
+                          const RtTFloat& tf) {
+  const float side = end.x - ini.x;
+  const float bxi = e.x - ini.x, bxe = e.x - end.x, byi = e.y - ini.y, bye = e.y - end.y, bzi = e.z - ini.z, bze = e.z - end.z;
+  const float sx = side * rc.ad[0], sy = side * rc.ad[1], sz = side * rc.ad[2];
+  const unsigned NEG = 0x80000000u;
+  const float dz_bxe = d.z * bxe, dz_bxi = d.z * bxi, dz_byi = d.z * byi, dz_bye = d.z * bye;
+  const float dx_bzi = d.x * bzi, dx_bze = d.x * bze, dx_byi = d.x * byi, dx_bye = d.x * bye;
+  const float dy_bzi = d.y * bzi, dy_bze = d.y * bze, dy_bxi = d.y * bxi, dy_bxe = d.y * bxe;
+  const float s0 = rt_face_score(dz_bxe, dx_bzi, dz_byi, dy_bzi, bzi, rc.sd[2], NEG, 0u, sz, tf.tdf[2]);
+  const float s1 = rt_face_score(dx_bzi, dz_bxi, dx_byi, dy_bxi, bxi, rc.sd[0], NEG, 0u, sx, tf.tdf[0]);
+  const float s2 = rt_face_score(dz_bxi, dx_bze, dz_byi, dy_bze, bze, rc.sd[2], 0u, 0u, sz, tf.tdf[2]);
+  const float s3 = rt_face_score(dx_bze, dz_bxe, dx_byi, dy_bxe, bxe, rc.sd[0], 0u, 0u, sx, tf.tdf[0]);
+  const float s4 = rt_face_score(dy_bxi, dx_bye, dy_bze, dz_bye, bye, rc.sd[1], 0u, 0u, sy, tf.tdf[1]);
+  const float s5 = rt_face_score(dy_bxi, dx_byi, dy_bzi, dz_byi, byi, rc.sd[1], 0u, NEG, sy, tf.tdf[1]);
+  return fmaxf(rt_max3(s0, s1, s2), rt_max3(s3, s4, s5));
+}
+
+// Complete decision from the score, falling back to the compare form on a boundary.
+RT_HD bool rt_node_accept_scored(const RtVec3& ini, const RtVec3& end, const RtVec3& e, const RtVec3& d, const RtRayConst& rc,
+                                 const RtTFloat& tf, float T) {
+  const float S = rt_node_score(ini, end, e, d, rc, tf);
+  if (S == 0.f) return rt_node_accept_exact(ini, end, e, d, rc, rt_t_const(rc, T));
+  return S > 0.f;
+}
+
+
+// ------------------------------------------------------------------------------------------------
+// Conservative slab classification in front of the exact node test.
+//
+// With t_p = (plane - e_k) / d_k for the six planes, tN = max of the three near values and tF = min
+// of the three far values, the box is crossed on [tN, tF].  The reference's six face tests can only
+// succeed at a crossing that lies within rounding distance of tN or tF, and every one of their
+// comparisons is, in t, a comparison of two of these plane distances with an error below
+// 2^-22 (|a| + |b|), a and b being plane distances of the axes involved (including the far plane of an
+// axis, because in-plane offsets are measured from a face corner).  So whenever every comparison that
+// matters is decided by more than E = 2^-17 (max |t_p| + T) the outcome of the reference test is known
+// without evaluating it:
+//   +1  accepted   (the entry face when tN > 0, else the exit face, passes with margin: t in (0,T), the
+//                   next near / far plane is further than E away, and the box is crossed for longer than E)
+//   -1  rejected   (missed by more than E, or entirely behind by more than E, or first reachable at t > T + E)
+//    0  undecided  -> rt_node_score / rt_node_accept_exact
+// Directions with a zero (or denormal-small) component give infinite or NaN distances; E is then
+// infinite or NaN, every comparison is false and the answer is 0.
+// ------------------------------------------------------------------------------------------------
+#define RT_SLAB_EPS 7.62939453125e-06f   /* 2^-17 */
+
+RT_HD float rt_med3(float a, float b, float c) { return fmaxf(fminf(a, b), fminf(fmaxf(a, b), c)); }
+
+// lo / hi: min and max corner of the cube; inv = 1 / d per component.
+RT_HD int rt_node_slab_class(const RtVec3& lo, const RtVec3& hi, const RtVec3& e, const RtVec3& inv, float T) {
+  const float x0 = (lo.x - e.x) * inv.x, x1 = (hi.x - e.x) * inv.x;
+  const float y0 = (lo.y - e.y) * inv.y, y1 = (hi.y - e.y) * inv.y;
+  const float z0 = (lo.z - e.z) * inv.z, z1 = (hi.z - e.z) * inv.z;
+  const float nx = fminf(x0, x1), fx = fmaxf(x0, x1), ny = fminf(y0, y1), fy = fmaxf(y0, y1), nz = fminf(z0, z1), fz = fmaxf(z0, z1);
+  const float tN = rt_max3(nx, ny, nz), tN2 = rt_med3(nx, ny, nz);
+  const float tF = rt_min3(fx, fy, fz), tF2 = rt_med3(fx, fy, fz);
+  // every in-plane comparison of the reference carries the magnitude of an offset measured from a corner of the
+  // face, i.e. up to the larger of the two plane distances of that axis: the margin scales with the largest of all six
+  const float M = fmaxf(rt_max3(fabsf(x0), fabsf(x1), fabsf(y0)), rt_max3(fabsf(y1), fabsf(z0), fabsf(z1)));
+  const float E = RT_SLAB_EPS * (M + T);
+  const float span = tF - tN;
+  const bool front = tN > 0.f;
+  const float tc = front ? tN : tF;                       // first reachable crossing
+  const float gap = front ? tN - tN2 : tF2 - tF;          // distance to the next plane of the same kind
+  const float a = rt_min3(T - tc, gap, span);
+  const bool acc = (a > E) & (tc > E);
+  const float r = rt_max3(-span, -tF, tc - T);
+  const bool rej = r > E;
+  return acc ? 1 : (rej ? -1 : 0);
+}
+
 #endif

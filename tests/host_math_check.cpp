@@ -19,13 +19,28 @@
 #include "../include/rt_amd.h"
 #include "../raytracer_amd/csrc/rt_math.h"
 
-static uint64_t n_node = 0, n_tri = 0, n_bad = 0, n_cand = 0, n_acc = 0;
+static uint64_t n_node = 0, n_tri = 0, n_bad = 0, n_cand = 0, n_acc = 0, n_zero = 0, n_amb = 0;
 
 static bool check_node(const RtVec3& ini, const RtVec3& end, const RtVec3& e, const RtVec3& d, float T) {
   const bool lit = rt_node_accept_literal(ini, end, e, d, T);
   const RtRayConst rc = rt_ray_const(d);
   const RtTConst tc = rt_t_const(rc, T);
-  const bool ex = rt_node_accept_exact(ini, end, e, d, rc, tc);
+  bool ex = rt_node_accept_exact(ini, end, e, d, rc, tc);
+  const RtTFloat tf = rt_t_float(rc, T);
+  const float S = rt_node_score(ini, end, e, d, rc, tf);
+  if (S == 0.f) n_zero++;
+  if (rt_node_accept_scored(ini, end, e, d, rc, tf, T) != ex) ex = !lit;   // a score mismatch is reported like any other
+  {   // the slab classification may abstain, never contradict
+    const RtVec3 lo = {ini.x, ini.y, end.z}, hi = {end.x, end.y, ini.z};
+    const RtVec3 inv = {1.f / d.x, 1.f / d.y, 1.f / d.z};
+    const int cls = rt_node_slab_class(lo, hi, e, inv, T);
+    if (cls == 0) n_amb++;
+    if ((cls > 0 && !lit) || (cls < 0 && lit)) {
+      if (n_bad < 10) printf("SLAB CONTRADICTION cls %d lit %d ini %.9g %.9g %.9g end %.9g %.9g %.9g e %.9g %.9g %.9g d %.9g %.9g %.9g T %.9g\n", cls, lit,
+             ini.x, ini.y, ini.z, end.x, end.y, end.z, e.x, e.y, e.z, d.x, d.y, d.z, T);
+      n_bad++;
+    }
+  }
   n_node++; n_acc += lit;
   if (lit != ex) {
     if (n_bad < 10)
@@ -118,7 +133,7 @@ static int run_scene(int ac, char** av) {
       trace(T, {P.x + ls[k].x * 0.001f, P.y + ls[k].y * 0.001f, P.z + ls[k].z * 0.001f}, ls[k], sh);
     }
   }
-  printf("checked %llu %llu mismatches %llu candidates %llu\n", (unsigned long long)n_node, (unsigned long long)n_tri, (unsigned long long)n_bad, (unsigned long long)n_cand);
+  printf("checked %llu %llu mismatches %llu candidates %llu score_zero %llu slab_undecided %llu\n", (unsigned long long)n_node, (unsigned long long)n_tri, (unsigned long long)n_bad, (unsigned long long)n_cand, (unsigned long long)n_zero, (unsigned long long)n_amb);
   return n_bad ? 1 : 0;
 }
 
@@ -148,6 +163,7 @@ static int run_random(int ac, char** av) {
     if (d.x == 0 && d.y == 0 && d.z == 0) d.y = 1.f;
     d = rt_normalized(d);
     if (mode == 7) { d = {U(rng), U(rng), U(rng)}; d = rt_normalized(d); }
+    if (pick(4) == 0) { float tiny = ldexpf(U(rng), -pick(40)); int k = pick(3); (k == 0 ? d.x : k == 1 ? d.y : d.z) = tiny; d = rt_normalized(d); }   // one nearly-zero component
     // running closest t: far, random, or exactly the crossing distance of one of the six faces (+- 1 ulp)
     float T = 64.f;
     int tm = pick(4);
@@ -160,7 +176,7 @@ static int run_random(int ac, char** av) {
     }
     check_node(ini, end, e, d, T);
   }
-  printf("checked %llu %llu mismatches %llu accepted %llu\n", (unsigned long long)n_node, (unsigned long long)n_tri, (unsigned long long)n_bad, (unsigned long long)n_acc);
+  printf("checked %llu %llu mismatches %llu accepted %llu score_zero %llu slab_undecided %llu\n", (unsigned long long)n_node, (unsigned long long)n_tri, (unsigned long long)n_bad, (unsigned long long)n_acc, (unsigned long long)n_zero, (unsigned long long)n_amb);
   return n_bad ? 1 : 0;
 }
 
