@@ -157,7 +157,7 @@ def main():
             ach = flop / world / (kernel_ms * 1e-3) / 1e12     # per launch: this rank's share of the frame
             roofline = {"bound": "valu_fp32", "achieved": ach, "peak": PEAK_FP32_TFLOPS, "unit": "TFLOP/s",
                         "frac": ach / PEAK_FP32_TFLOPS, "traffic": None,
-                        "kernel": "render_tiles", "kernel_ms": kernel_ms, "flop_per_ray": flop / ref["rays"],
+                        "kernel": "render_wave", "kernel_ms": kernel_ms, "flop_per_ray": flop / ref["rays"],
                         "algorithmic_GBps": byts / world / (kernel_ms * 1e-3) / 1e9, "hbm_peak_GBps": PEAK_HBM_GBS}
         out = {
             "metric": "Mrays/s at 3840x2160 meshDragon", "value": mrays, "unit": "Mrays/s", "n_gpus": world,

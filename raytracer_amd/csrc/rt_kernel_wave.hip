@@ -224,6 +224,7 @@ __global__ __launch_bounds__(RT_BLOCK, RT_WAVES_PER_SIMD) void render_wave(
     const int32_t* __restrict__ mesh_mat_first, const int32_t* __restrict__ mesh_mat_count, int n_spheres, int n_lights, int has_oct,
     uint8_t* __restrict__ rgb, int32_t* __restrict__ ids, float* __restrict__ ts, unsigned long long* __restrict__ counters) {
   __shared__ float parked[ShadeState<BOUNCE>::WORDS * RT_BLOCK];
+  __shared__ uint32_t pack[RT_BLOCK / 64][48];
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
   float* my_park = &parked[tid];
   WaveStack st = {0u, 0u, 0u, 0u};
@@ -427,13 +428,32 @@ __global__ __launch_bounds__(RT_BLOCK, RT_WAVES_PER_SIMD) void render_wave(
     }
   }
 
-  if (valid) {
-    const size_t p = ((size_t)orow * W + col) * 3;
-    for (int k = 0; k < 3; k++) {   // camera.cu:113-122; NaN < 1 is false, so NaN -> 1 -> 255
-      const float v = (sh.color[k] < 1.f ? sh.color[k] : 1.f) * 255.f;
-      rgb[p + k] = v < 0.f ? (uint8_t)0 : (uint8_t)(int)v;
+  // ---- quantise (camera.cu:113-122; NaN < 1 is false, so NaN -> 1 -> 255) and store -------------------------
+  // A tile row is 24 contiguous bytes.  The wave packs its 192 bytes through LDS and stores them as 48 aligned
+  // dwords instead of 192 single bytes (each byte store is its own partial write to memory).
+  uint8_t q[3];
+  for (int k = 0; k < 3; k++) {
+    const float v = (sh.color[k] < 1.f ? sh.color[k] : 1.f) * 255.f;
+    q[k] = v < 0.f ? (uint8_t)0 : (uint8_t)(int)v;
+  }
+  if (valid) tl.rays++;   // the primary ray
+  const int col0 = blockIdx.x * RT_TILE_W + (wave & 1) * 8, lrow0 = blockIdx.y * RT_TILE_H + (wave >> 1) * 8;
+  const int last_row = rows.row0 + ((lrow0 + 7) / rows.band_rows) * rows.band_stride + (lrow0 + 7) % rows.band_rows;
+  const bool whole = (W & 3) == 0 && col0 + 8 <= W && lrow0 + 8 <= rows.n_local && last_row < H &&
+                     (lrow0 / rows.band_rows) == ((lrow0 + 7) / rows.band_rows);   // wave-uniform
+  if (whole) {
+    uint8_t* pk = (uint8_t*)pack[wave];
+    pk[lane * 3 + 0] = q[0]; pk[lane * 3 + 1] = q[1]; pk[lane * 3 + 2] = q[2];
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    if (lane < 48) {
+      const int r = lane / 6, j = lane - 6 * r;
+      const int orow0 = rows.compact ? lrow0 : (rows.row0 + (lrow0 / rows.band_rows) * rows.band_stride + lrow0 % rows.band_rows);
+      uint32_t* dst = (uint32_t*)(rgb + ((size_t)(orow0 + r) * W + col0) * 3) + j;
+      *dst = pack[wave][r * 6 + j];
     }
-    tl.rays++;   // the primary ray
+  } else if (valid) {
+    const size_t p = ((size_t)orow * W + col) * 3;
+    rgb[p] = q[0]; rgb[p + 1] = q[1]; rgb[p + 2] = q[2];
   }
 
   // work counters: wave reduction, one atomic per wave and counter

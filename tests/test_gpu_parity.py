@@ -21,9 +21,10 @@ def _rgb_close(a, b):
 
 
 def _check_scene(name, w, h, depth=3):
-    o = OracleScene("scenes/%s.json" % name, w, h, depth)
+    path = name if name.endswith(".json") else "scenes/%s.json" % name
+    o = OracleScene(path, w, h, depth)
     orgb, oids, ots, oct_ = o.render(threads=8)
-    ds = rt.DeviceScene(rt.Scene("scenes/%s.json" % name, w, h, depth))
+    ds = rt.DeviceScene(rt.Scene(path, w, h, depth))
     # instrumented variant: full traversals, counts every test
     rgb, ids, ts, st = ds.render_host(flags=rt.RT_RENDER_COUNT_TESTS)
     assert np.array_equal(ids, oids), "primary hit ids differ on %d pixels" % int((ids != oids).sum())
@@ -153,3 +154,31 @@ def test_band_partition_reproduces_the_full_image(nranks):
     assert np.array_equal(rt.assemble_bands(tiles, h, 16), full)
     assert np.array_equal(rt.assemble_bands(id_tiles, h, 16), fids)
     assert rays == fst["rays"]
+
+
+SPOT_SCENE = """{
+  "camera": {"fov": 50.0, "position": [0, 6, 14], "up": [0, 1, 0], "target": [0, 1, 0]},
+  "objects": [
+    {"__type__": "mesh", "file_path": "meshes/large_plane.obj", "materials": ["white_lambert", "white_bph_100"]},
+    {"__type__": "mesh", "file_path": "meshes/sphere.obj", "materials": ["copper_lambert", "copper_bph_100"],
+     "scaling": [2, 2, 2], "rotation": [10, 20, 30], "translation": [-2, 2, 0]},
+    {"__type__": "sphere", "position": [3, 1.5, 1], "radius": 1.5, "materials": ["blue_lambert", "blue_bph_1000"]}
+  ],
+  "lights": [
+    {"__type__": "spot_light", "position": [0, 9, 4], "color": [0.9, 0.9, 0.8], "angle": 55.0, "direction": [0, -1, -0.3]},
+    {"__type__": "spot_light", "position": [-6, 5, 6], "color": [0.3, 0.5, 0.9], "angle": 30.0, "direction": [0.7, -0.5, -0.7]},
+    {"__type__": "point_light", "position": [5, 8, 5], "color": [0.2, 0.2, 0.2]},
+    {"__type__": "ambient_light", "color": [0.1, 0.1, 0.1]}
+  ],
+  "params": {"background_color": [0.1, 0.2, 0.3], "enable_shadows": "true"}
+}"""
+
+
+def test_spot_lights_synthetic_scene(tmp_path):
+    # No scene of the reference uses a spot light, although its routines implement one (lights.cu:281-295,335-350).
+    p = tmp_path / "spots.json"
+    p.write_text(SPOT_SCENE)
+    for shadows in ("true", "false"):
+        q = tmp_path / ("spots_%s.json" % shadows)
+        q.write_text(SPOT_SCENE.replace('"enable_shadows": "true"', '"enable_shadows": "%s"' % shadows))
+        _check_scene(str(q), 200, 120)
