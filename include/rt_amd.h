@@ -63,6 +63,9 @@ typedef struct rt_stats {
   uint64_t node_tests, leaf_visits, tri_tests, sphere_tests;
   uint64_t ub_leave_level0, ub_level_overflow, ub_stack_overflow;
   uint64_t rays_traced;   /* traversals actually run: one shadow ray serves every material of a hit point */
+  /* instrumented production kernel only, counted per WAVE: traversals, node iterations, of which exact-test,
+   * of which boundary compare form, triangle iterations, reaching stage 2, stage 3, the quotient stage */
+  uint64_t wave_paths[8];
   float kernel_ms;   /* HIP-event time of the render kernels of this call (0 unless RT_RENDER_TIME) */
 } rt_stats;
 

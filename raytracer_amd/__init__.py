@@ -51,10 +51,12 @@ class SceneInfo(C.Structure):
 class Stats(C.Structure):
     _fields_ = [(n, C.c_uint64) for n in (
         "rays", "shadow_rays", "node_tests", "leaf_visits", "tri_tests", "sphere_tests", "ub_leave_level0",
-        "ub_level_overflow", "ub_stack_overflow", "rays_traced")] + [("kernel_ms", C.c_float)]
+        "ub_level_overflow", "ub_stack_overflow", "rays_traced")] + [("wave_paths", C.c_uint64 * 8), ("kernel_ms", C.c_float)]
 
     def as_dict(self):
-        return {n: getattr(self, n) for n, _ in self._fields_}
+        d = {n: getattr(self, n) for n, _ in self._fields_ if n != "wave_paths"}
+        d["wave_paths"] = list(self.wave_paths)
+        return d
 
 
 _lib = None

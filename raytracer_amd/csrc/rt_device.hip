@@ -57,14 +57,14 @@ extern "C" int rt_scene_upload(const rt_scene* s, int device, rt_dscene** out) {
   if (hipGetDeviceCount(&n_dev) != hipSuccess || n_dev < 1) { rt_set_error("no HIP device is visible; the render path has no CPU fallback"); return RT_ERR_DEVICE; }
   if (device < 0 || device >= n_dev) { rt_set_error("device index out of range"); return RT_ERR_ARG; }
   HIP_TRY(hipSetDevice(device));
-  static_assert(sizeof(RtNode) == 32 && sizeof(RtTriGeom) == 48 && sizeof(RtTriShade) == 64 && sizeof(RtTriLeaf) == 64, "record sizes");
+  static_assert(sizeof(RtNode) == 32 && sizeof(RtWaveNode) == 32 && sizeof(RtTriGeom) == 48 && sizeof(RtTriShade) == 64 && sizeof(RtTriLeaf) == 64, "record sizes");
   rt_dscene* d = new rt_dscene();
   d->device = device; d->info = s->info;
   RtDeviceView& V = d->view; memset(&V, 0, sizeof V);
   V.cam = s->cam;
   int rc;
 #define UP(field, vec) if ((rc = upload(d, vec, (const void**)&V.field)) != RT_OK) { rt_dscene_destroy(d); return rc; }
-  UP(nodes, s->nodes) UP(leaf_refs, s->leaf_refs) UP(tri_geom, s->tri_geom) UP(tri_leaf, s->tri_leaf) UP(tri_shade, s->tri_shade)
+  UP(nodes, s->nodes) UP(wnodes, s->wnodes) UP(leaf_refs, s->leaf_refs) UP(tri_geom, s->tri_geom) UP(tri_leaf, s->tri_leaf) UP(tri_shade, s->tri_shade)
   UP(spheres, s->spheres) UP(lights, s->lights) UP(materials, s->materials) UP(mat_index, s->mat_index)
   UP(mesh_mat_first, s->mesh_mat_first) UP(mesh_mat_count, s->mesh_mat_count)
 #undef UP
@@ -105,6 +105,7 @@ static int launch_render(rt_dscene* d, const RowMap& rows, uint8_t* d_rgb, int32
     stats->tri_tests = h[C_TRI]; stats->sphere_tests = h[C_SPH]; stats->ub_leave_level0 = h[C_UB_LEAVE];
     stats->ub_level_overflow = h[C_UB_OVER]; stats->ub_stack_overflow = h[C_UB_STACK];
     stats->rays_traced = (flags & RT_RENDER_LITERAL) ? h[C_RAYS] : h[C_TRACED]; stats->kernel_ms = ms;
+    for (int k = 0; k < 8; k++) stats->wave_paths[k] = h[C_W_TRACE + k];
   }
   return RT_OK;
 }

@@ -51,6 +51,12 @@ struct RtSphere {     // 32 B
 //   b = end.x end.y end.z bits(count)   count: branch -> -1, leaf -> number of triangles (0..50)
 struct RtNode { float a[4]; float b[4]; };
 
+// The same node as the wave-synchronous kernel reads it, 32 B = one 8-dword scalar load.  The two planes of an
+// axis sit in adjacent dwords so that a packed-fp32 instruction can take them straight from an SGPR pair.
+//   lo.x hi.x lo.y hi.y | lo.z hi.z first meta     (lo / hi = min / max corner: ini = lo.x lo.y hi.z, end = hi.x hi.y lo.z)
+//   meta: leaf -> number of triangles (0..50); branch -> 0x80000000 | bit c set when child c is not an empty leaf
+struct RtWaveNode { float lohi[6]; int32_t first; uint32_t meta; };
+
 // Triangle intersection record, 48 B = three 16-byte loads:
 //   v0.xyz, e1.xyz, e2.xyz (e1 = v1 - v0, e2 = v2 - v0 rounded to float, the first
 //   six operations of triangle.cu:118-120), then mesh index and two pads.
@@ -70,6 +76,7 @@ struct rt_scene {
   std::vector<int32_t> mat_index;                 // concatenated material lists (spheres, then meshes)
   std::vector<int32_t> mesh_mat_first, mesh_mat_count;
   std::vector<RtNode> nodes;                      // nodes[0] = root (always a branch) when non-empty
+  std::vector<RtWaveNode> wnodes;                 // nodes in the wave kernel's layout (same indices, same pad record)
   std::vector<int32_t> leaf_refs;
   std::vector<RtTriGeom> tri_geom;
   std::vector<RtTriLeaf> tri_leaf;                // intersection records repeated in leaf order (index space of leaf_refs), plus one pad record

@@ -20,7 +20,7 @@
 
 namespace {
 
-struct Tally { uint32_t rays, shadow, node, leaf, tri, sph, traced; };
+struct Tally { uint32_t rays, shadow, node, leaf, tri, sph, traced; uint32_t w[8]; };   // w: wave-level path counts (lane 0, instrumented variant)
 
 // The wave's traversal stack lives in four VGPRs: entry i is held by lane i (depth <= 20 < 64) and is
 // written with a lane-select and read with v_readlane, whose lane index is wave-uniform.  No LDS, no memory latency.
@@ -42,69 +42,101 @@ __device__ __forceinline__ void trace_wave(const float4* __restrict__ nodes, con
                                            const RtSphere* __restrict__ spheres, int n_spheres, bool has_oct, bool want,
                                            const RtVec3& e, const RtVec3& d, float stop_t, Hit& hit, WaveStack& st,
                                            int lane, Tally& tl) {
-  const uint64_t lane_bit = 1ull << lane;
-  uint64_t live = __ballot(want);
+  // Lane sets are kept as wave-uniform 64-bit masks in SGPRs (who still has an undecided ray, who entered the
+  // current branch, who accepted the current node, ...); they are combined on the scalar unit and only turned
+  // back into a per-lane predicate on the rare paths that need one.
+  uint64_t live = __builtin_amdgcn_ballot_w64(want);
   if (!live) return;
+  if (COUNT) tl.w[0]++;
   RtTFloat tf = rt_t_float(rt_ray_const(d), hit.t);
   const RtVec3 inv = {1.f / d.x, 1.f / d.y, 1.f / d.z};   // only feeds the conservative classification
-  bool mine_live = want;
+  const unsigned zmask = (d.x == 0.f ? 1u : 0u) | (d.y == 0.f ? 2u : 0u) | (d.z == 0.f ? 4u : 0u);
+  const bool any_zero = (__builtin_amdgcn_ballot_w64(zmask != 0u) & live) != 0ull;
 
   if (has_oct) {
-    uint32_t top_first = uni(__float_as_uint(nodes[0].w)), top_cur = 0;   // the root is entered without a test (ray.cu:36-38)
+    // The walk goes over the children of one branch at a time: `rem` holds the children still to be tested (bit c =
+    // child c, lowest first = the reference's order 0..7).  Empty leaves are left out of `rem` from the start: testing
+    // one has no effect on any result, only on the node-test count, so the instrumented variant keeps them.
+    uint32_t top_first = uni(__float_as_uint(nodes[1].z));   // the root is entered without a test (ray.cu:36-38)
+    uint32_t rem = COUNT ? 0xffu : (uni(__float_as_uint(nodes[1].w)) & 0xffu);
     uint64_t top_mask = live;
     int sp = 0;
-    // Node records reach the SGPRs through the scalar cache.  The record of the next sibling is requested
-    // before the current one is evaluated, so its latency hides behind ~100 VALU instructions; only the
-    // first child after a descent or an ascent is waited for.  (Both arrays end with a pad record.)
-    uint32_t pre_idx = 0xffffffffu;
-    float4 pre_a = {0, 0, 0, 0}, pre_b = {0, 0, 0, 0};
+    // Node records reach the SGPRs through the scalar cache.  The record of the child that will be tested next is
+    // always requested as soon as it is known (next sibling: before the current child is classified; first child of
+    // a branch: on descent or ascent), so its latency hides behind the classification.
+    float4 nx_a = {0, 0, 0, 0}, nx_b = {0, 0, 0, 0};
+    { const uint32_t i = top_first + (uint32_t)__builtin_ctz(rem | 0x100u); nx_a = nodes[2 * i]; nx_b = nodes[2 * i + 1]; }
     for (;;) {
-      if (top_cur == 8u || (top_mask & live) == 0ull) {   // branch exhausted, or every lane that entered it is decided
+      const uint64_t mine_m = top_mask & live;
+      if (rem == 0u || mine_m == 0ull) {   // branch exhausted, or every lane that entered it is decided
         if (sp == 0) break;
         sp--;
-        top_first = __builtin_amdgcn_readlane(st.first, sp); top_cur = __builtin_amdgcn_readlane(st.cur, sp);
+        top_first = __builtin_amdgcn_readlane(st.first, sp); rem = __builtin_amdgcn_readlane(st.cur, sp);
         top_mask = ((uint64_t)(uint32_t)__builtin_amdgcn_readlane(st.mask_hi, sp) << 32) | (uint32_t)__builtin_amdgcn_readlane(st.mask_lo, sp);
+        const uint32_t i = top_first + (uint32_t)__builtin_ctz(rem);   // entries are only pushed with children left
+        nx_a = nodes[2 * i]; nx_b = nodes[2 * i + 1];
         continue;
       }
-      const uint32_t child = top_first + top_cur;
-      top_cur++;
-      float4 na, nb;
-      if (child == pre_idx) { na = pre_a; nb = pre_b; }
-      else { na = nodes[2 * child]; nb = nodes[2 * child + 1]; }
-      pre_idx = child + 1u;
-      pre_a = nodes[2 * pre_idx]; pre_b = nodes[2 * pre_idx + 1];
-      const bool mine = mine_live && (top_mask & lane_bit) != 0ull;
-      if (COUNT && mine) tl.node++;
-      const RtVec3 ini = {na.x, na.y, na.z}, end = {nb.x, nb.y, nb.z};
+      rem &= rem - 1u;
+      const float4 na = nx_a, nb = nx_b;
+      if (rem != 0u) { const uint32_t i = top_first + (uint32_t)__builtin_ctz(rem); nx_a = nodes[2 * i]; nx_b = nodes[2 * i + 1]; }
+      if (COUNT) { tl.w[1]++; if ((mine_m >> lane) & 1ull) tl.node++; }
       // conservative slab classification first; the exact test only where some lane is within rounding of a boundary
-      const int cls = rt_node_slab_class({na.x, na.y, nb.z}, {nb.x, nb.y, na.z}, e, inv, hit.t);
-      bool acc = mine & (cls > 0);
-      if (__ballot(mine & (cls == 0))) {
-        const float S = rt_node_score(ini, end, e, d, rt_ray_const(d), tf);
-        bool accS = S > 0.f;
-        if (__ballot(mine & (cls == 0) & (S == 0.f))) {   // a boundary case: settle it with the compare form
-          if (S == 0.f) accS = rt_node_accept_exact(ini, end, e, d, rt_ray_const(d), rt_t_const(rt_ray_const(d), hit.t));
+      uint64_t acc_m, und_m;
+      if (!any_zero) {
+        bool c_acc, c_rej;
+        rt_node_slab_fast(na.x, na.y, na.z, na.w, nb.x, nb.y, e, inv, hit.t, c_acc, c_rej);
+#ifdef RT_ABL_NODE2
+        {   // ablation: evaluate the classification a second time on values the compiler cannot fold
+          float t2 = hit.t; asm volatile("" : "+v"(t2));
+          bool a2, r2;
+          rt_node_slab_fast(na.x, na.y, na.z, na.w, nb.x, nb.y, e, inv, t2, a2, r2);
+          asm volatile("" :: "s"(__builtin_amdgcn_ballot_w64(a2)), "s"(__builtin_amdgcn_ballot_w64(r2)));
         }
-        if (cls == 0) acc = mine & accS;
+#endif
+        acc_m = __builtin_amdgcn_ballot_w64(c_acc) & mine_m;
+        und_m = mine_m & ~(acc_m | __builtin_amdgcn_ballot_w64(c_rej));
+      } else {
+        bool c_acc, c_und;
+        rt_node_slab_class2({na.x, na.z, nb.x}, {na.y, na.w, nb.y}, e, inv, hit.t, true, zmask, c_acc, c_und);
+        acc_m = __builtin_amdgcn_ballot_w64(c_acc) & mine_m;
+        und_m = __builtin_amdgcn_ballot_w64(c_und) & mine_m;
       }
-      const uint64_t m = __ballot(acc);
-      if (!m) continue;
-      const uint32_t first = uni(__float_as_uint(na.w));
-      const int32_t count = (int32_t)uni(__float_as_uint(nb.w));
-      if (count < 0) {   // branch: descend; the parent is only kept if it has children left
-        if (top_cur < 8u) {
+      if (und_m) {
+        if (COUNT) tl.w[2]++;
+        const RtVec3 ini = {na.x, na.z, nb.y}, end = {na.y, na.w, nb.x};
+        const float S = rt_node_score(ini, end, e, d, rt_ray_const(d), tf);
+        uint64_t pos_m = __builtin_amdgcn_ballot_w64(S > 0.f);
+        const uint64_t tie_m = __builtin_amdgcn_ballot_w64(S == 0.f) & und_m;
+        if (tie_m) {   // a boundary case: settle it with the compare form
+          if (COUNT) tl.w[3]++;
+          const bool ex = rt_node_accept_exact(ini, end, e, d, rt_ray_const(d), rt_t_const(rt_ray_const(d), hit.t));
+          pos_m = (pos_m & ~tie_m) | (__builtin_amdgcn_ballot_w64(ex) & tie_m);
+        }
+        acc_m |= pos_m & und_m;
+      }
+      if (!acc_m) continue;
+      const uint32_t first = uni(__float_as_uint(nb.z));
+      const uint32_t meta = uni(__float_as_uint(nb.w));
+      if (meta & 0x80000000u) {   // branch: descend; the parent is only kept if it has children left
+        const uint32_t crem = COUNT ? 0xffu : (meta & 0xffu);
+        if (crem == 0u) continue;
+        if (rem != 0u) {
           const bool slot = lane == sp;   // lane sp keeps entry sp
-          st.first = slot ? top_first : st.first; st.cur = slot ? top_cur : st.cur;
+          st.first = slot ? top_first : st.first; st.cur = slot ? rem : st.cur;
           st.mask_lo = slot ? (uint32_t)top_mask : st.mask_lo; st.mask_hi = slot ? (uint32_t)(top_mask >> 32) : st.mask_hi;
           sp++;
         }
-        top_first = first; top_cur = 0; top_mask = m;
+        top_first = first; rem = crem; top_mask = acc_m;
+        const uint32_t i = top_first + (uint32_t)__builtin_ctz(rem);
+        nx_a = nodes[2 * i]; nx_b = nodes[2 * i + 1];
         continue;
       }
-      // leaf: every triangle in insertion order (octtree.cu:264-274); all lanes in `m` test the same triangle
-      if (COUNT && acc) { tl.leaf++; tl.tri += (uint32_t)count; }
+      const int32_t count = (int32_t)meta;
+      // leaf: every triangle in insertion order (octtree.cu:264-274); all lanes in acc_m test the same triangle
+      if (COUNT && ((acc_m >> lane) & 1ull)) { tl.leaf++; tl.tri += (uint32_t)count; }
       if (count == 0) continue;
-      bool changed = false;
+      uint64_t changed_m = 0ull;
       const float4* tp = tri_leaf + 4 * (size_t)first;
       float4 g0 = tp[0], g1 = tp[1], g2 = tp[2];
       for (int32_t k = 0; k < count; k++) {
@@ -113,6 +145,7 @@ __device__ __forceinline__ void trace_wave(const float4* __restrict__ nodes, con
         const RtVec3 v0 = {g0.x, g0.y, g0.z}, e1 = {g0.w, g1.x, g1.y}, e2 = {g1.z, g1.w, g2.x};
         const int32_t tri_id = (int32_t)__float_as_uint(g2.y);
         g0 = h0; g1 = h1; g2 = h2;
+        if (COUNT) tl.w[4]++;
         // stage 1: determinant and beta numerator (triangle.cu:117-131, first column of cofactors)
         const RtVec3 b = {e.x - v0.x, e.y - v0.y, e.z - v0.z};
         const RtVec3 c2 = {-d.x, -d.y, -d.z};
@@ -125,49 +158,64 @@ __device__ __forceinline__ void trace_wave(const float4* __restrict__ nodes, con
         const unsigned s = rt_bits(n.det) & 0x80000000u;
         const float ad = fabsf(n.det);
         const float nbs = rt_from_bits(rt_bits(n.nb) ^ s);
-        // 0 <= beta <= 1 with det != 0  <=>  min(nbs, ad - nbs) >= 0 and ad > 0
-        bool pass = acc & (ad > 0.f) & (fminf(nbs, ad - nbs) >= 0.f);
-        if (!__ballot(pass)) continue;
+        // 0 <= beta <= 1 with det != 0  <=>  min(nbs, |det| - nbs) >= 0 and |det| > 0
+        uint64_t pass_m = __builtin_amdgcn_ballot_w64(ad > 0.f) & __builtin_amdgcn_ballot_w64(fminf(nbs, ad - nbs) >= 0.f) & acc_m;
+#ifdef RT_ABL_TRI2
+        {   // ablation: stage 1 a second time
+          RtVec3 e_ = e; asm volatile("" : "+v"(e_.x), "+v"(e_.y), "+v"(e_.z));
+          const RtVec3 b_ = {e_.x - v0.x, e_.y - v0.y, e_.z - v0.z};
+          const float det_ = e1.x * m00 + e1.y * m10 + e1.z * m20;
+          const float nb_ = m00 * b_.x + m10 * b_.y + m20 * b_.z;
+          const float q_ = fminf(rt_from_bits(rt_bits(nb_) ^ (rt_bits(det_) & 0x80000000u)), fabsf(det_) - nb_);
+          asm volatile("" :: "v"(q_));
+        }
+#endif
+        if (!pass_m) continue;
+        if (COUNT) tl.w[5]++;
         // stage 2: gamma numerator
         const float m01 = -e1.y * c2.z + e1.z * c2.y;
         const float m11 = e1.x * c2.z - e1.z * c2.x;
         const float m21 = -e1.x * c2.y + e1.y * c2.x;
         n.ng = m01 * b.x + m11 * b.y + m21 * b.z;
         const float ngs = rt_from_bits(rt_bits(n.ng) ^ s);
-        pass = pass & (fminf(ngs, ad - ngs) >= 0.f);
-        if (!__ballot(pass)) continue;
+        pass_m &= __builtin_amdgcn_ballot_w64(fminf(ngs, ad - ngs) >= 0.f);
+        if (!pass_m) continue;
+        if (COUNT) tl.w[6]++;
         // stage 3: t numerator; t > 0, and t clearly beyond the closest hit is rejected without dividing
         const float m02 = e1.y * e2.z - e1.z * e2.y;
         const float m12 = -e1.x * e2.z + e1.z * e2.x;
         const float m22 = e1.x * e2.y - e1.y * e2.x;
         n.nt = m02 * b.x + m12 * b.y + m22 * b.z;
         const float nts = rt_from_bits(rt_bits(n.nt) ^ s);
-        pass = pass & (nts > 0.f) & (nts <= (hit.t * ad) * 1.000001f);
-        if (!__ballot(pass)) continue;
-        if (pass) {   // the reference's quotients decide (triangle.cu:131-137)
+        pass_m &= __builtin_amdgcn_ballot_w64(nts > 0.f) & __builtin_amdgcn_ballot_w64(nts <= (hit.t * ad) * 1.000001f);
+        if (!pass_m) continue;
+        if (COUNT) tl.w[7]++;
+        if ((pass_m >> lane) & 1ull) {   // the reference's quotients decide (triangle.cu:131-137)
           float t, bet, gam;
-          if (rt_triangle_finish(n, hit.t, t, bet, gam)) {
-            hit.t = t; hit.prim = tri_id; hit.bet = bet; hit.gam = gam;
-            changed = true;
-          }
+          if (rt_triangle_finish(n, hit.t, t, bet, gam)) { hit.t = t; hit.prim = tri_id; hit.bet = bet; hit.gam = gam; }
         }
+        changed_m |= pass_m;   // a superset of the lanes whose t changed is enough: their bounds are simply refreshed
       }
-      if (__ballot(changed)) {
-        if (changed) {
+      if (changed_m) {
+        bool done = false;
+        if ((changed_m >> lane) & 1ull) {
           tf = rt_t_float(rt_ray_const(d), hit.t);
-          if (stop_t >= 0.f && hit.t < stop_t) mine_live = false;
+          done = stop_t >= 0.f && hit.t < stop_t;
         }
-        live = __ballot(mine_live);
+        live &= ~__builtin_amdgcn_ballot_w64(done);
         if (!live) return;
       }
     }
   }
-  for (int32_t s = 0; s < n_spheres; s++) {   // ray.cu:52-53
-    if (mine_live) {
-      if (COUNT) tl.sph++;
-      if (rt_sphere_test(ld3(spheres[s].c), spheres[s].r, e, d, hit.t)) {
-        hit.prim = -2 - s;
-        if (stop_t >= 0.f && hit.t < stop_t) mine_live = false;
+  if (n_spheres > 0) {
+    bool mine_live = ((live >> lane) & 1ull) != 0ull;
+    for (int32_t s = 0; s < n_spheres; s++) {   // ray.cu:52-53
+      if (mine_live) {
+        if (COUNT) tl.sph++;
+        if (rt_sphere_test(ld3(spheres[s].c), spheres[s].r, e, d, hit.t)) {
+          hit.prim = -2 - s;
+          if (stop_t >= 0.f && hit.t < stop_t) mine_live = false;
+        }
       }
     }
   }
@@ -234,7 +282,7 @@ __global__ __launch_bounds__(RT_BLOCK, RT_WAVES_PER_SIMD) void render_wave(
   const int row = rows.row0 + (lrow / rows.band_rows) * rows.band_stride + lrow % rows.band_rows;
   const int orow = rows.compact ? lrow : row;
   const bool valid = col < W && lrow < rows.n_local && row < H;
-  Tally tl = {0, 0, 0, 0, 0, 0, 0};
+  Tally tl = {0, 0, 0, 0, 0, 0, 0, {0, 0, 0, 0, 0, 0, 0, 0}};
   const RtCamera& c = cam;
 
   // view handed to the helpers of rt_kernels.h
@@ -267,7 +315,7 @@ __global__ __launch_bounds__(RT_BLOCK, RT_WAVES_PER_SIMD) void render_wave(
   BounceRay rstack[BOUNCE ? RT_RAY_STACK : 1];
   int rsp = 0;
 
-  while (__ballot(phase != PH_DONE)) {
+  while (__builtin_amdgcn_ballot_w64(phase != PH_DONE)) {
     // ---- trace the pending rays of the wave ---------------------------------------------------------
     Hit h = {RT_INF, -1, 0.f, 0.f};
     {
@@ -465,6 +513,7 @@ __global__ __launch_bounds__(RT_BLOCK, RT_WAVES_PER_SIMD) void render_wave(
     for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
     if (lane == 0 && v) atomicAdd(&counters[slot[k]], (unsigned long long)v);
   }
+  if (COUNT && lane == 0) for (int k = 0; k < 8; k++) if (tl.w[k]) atomicAdd(&counters[C_W_TRACE + k], (unsigned long long)tl.w[k]);
 }
 
 }  // namespace
@@ -473,7 +522,7 @@ void rt_launch_wave_kernel(const RtDeviceView& V, const RowMap& rows, bool bounc
                            float* ts, unsigned long long* counters, hipStream_t stream) {
   const dim3 grid((V.cam.width + RT_TILE_W - 1) / RT_TILE_W, (rows.n_local + RT_TILE_H - 1) / RT_TILE_H), block(RT_BLOCK);
 #define LAUNCH(B, C)                                                                                                             \
-  hipLaunchKernelGGL((render_wave<B, C>), grid, block, 0, stream, V.cam, rows, V.nodes, V.tri_leaf, V.tri_geom, V.tri_shade,     \
+  hipLaunchKernelGGL((render_wave<B, C>), grid, block, 0, stream, V.cam, rows, V.wnodes, V.tri_leaf, V.tri_geom, V.tri_shade,     \
                      V.spheres, V.lights, V.materials, V.mat_index, V.mesh_mat_first, V.mesh_mat_count, V.n_spheres, V.n_lights, \
                      V.has_oct, rgb, ids, ts, counters)
   if (bounce && count) LAUNCH(true, true);

@@ -15,6 +15,7 @@
 struct RtDeviceView {
   RtCamera cam;
   const float4* nodes;        // 2 per node
+  const float4* wnodes;       // 2 per node, RtWaveNode layout
   const int32_t* leaf_refs;
   const float4* tri_geom;     // 3 per triangle, indexed by triangle id
   const float4* tri_leaf;     // 4 per leaf reference (RtTriLeaf), in leaf order (same index space as leaf_refs)
@@ -33,7 +34,9 @@ struct RtDeviceView {
 // when `compact` is 0 and at row lr of a band-packed buffer when it is 1.
 struct RowMap { int32_t row0, band_rows, band_stride, n_local, compact, pad; };
 
-enum { C_RAYS = 0, C_SHADOW, C_NODE, C_LEAF, C_TRI, C_SPH, C_UB_LEAVE, C_UB_OVER, C_UB_STACK, C_TRACED, C_COUNT };
+enum { C_RAYS = 0, C_SHADOW, C_NODE, C_LEAF, C_TRI, C_SPH, C_UB_LEAVE, C_UB_OVER, C_UB_STACK, C_TRACED,
+       // wave-level iteration counts of the instrumented production kernel (how often each code path runs)
+       C_W_TRACE, C_W_NODE, C_W_NODE_EXACT, C_W_NODE_TIE, C_W_TRI, C_W_TRI_S2, C_W_TRI_S3, C_W_TRI_FIN, C_COUNT };
 
 struct Hit {
   float t;

@@ -246,6 +246,15 @@ RT_HD RtTFloat rt_t_float(const RtRayConst& r, float T) {
 }
 RT_HD float rt_min3(float a, float b, float c) { return fminf(fminf(a, b), c); }
 RT_HD float rt_max3(float a, float b, float c) { return fmaxf(fmaxf(a, b), c); }
+// Median of three.  On the device this is one v_med3_f32; the two forms agree whenever no input is a NaN, and the
+// only caller makes its decision "undecided" in every case where a NaN can occur.
+RT_HD float rt_med3(float a, float b, float c) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  return __builtin_amdgcn_fmed3f(a, b, c);
+#else
+  return fmaxf(fminf(a, b), fminf(fmaxf(a, b), c));
+#endif
+}
 
 RT_HD float rt_face_score(float dk_bi, float di_bk, float dk_bj, float dj_bk, float bk, unsigned sdk, unsigned neg_i,
                           unsigned neg_j, float side_adk, float tdfk) {
@@ -302,14 +311,35 @@ RT_HD bool rt_node_accept_scored(const RtVec3& ini, const RtVec3& end, const RtV
 // ------------------------------------------------------------------------------------------------
 #define RT_SLAB_EPS 7.62939453125e-06f   /* 2^-17 */
 
-RT_HD float rt_med3(float a, float b, float c) { return fmaxf(fminf(a, b), fminf(fmaxf(a, b), c)); }
+// A direction component that is exactly zero.  Faces perpendicular to that axis can never pass (their solve
+// divides by zero), and for the other faces the in-plane condition on that axis degenerates to
+// 0 <= fl(e - lo) <= side for faces measured from the low corner and 0 <= fl(hi - e) <= side for faces measured
+// from the high corner (fl(|d| b) <= side |d| <=> b <= side when side is a power of two).  Strictly inside
+// for both conventions: the axis imposes nothing.  Outside for both: nothing can pass.  Otherwise: undecided.
+//   returns +1 neutral, -1 rejects the node, 0 undecided
+RT_HD int rt_zero_axis(float lo, float hi, float e, float side) {
+  const float A = e - lo, B = hi - e;
+  const float in = fminf(fminf(A, side - A), fminf(B, side - B));
+  const float out = fmaxf(fminf(-A, B - side), fminf(-B, A - side));
+  return in > 0.f ? 1 : (out > 0.f ? -1 : 0);
+}
 
-// lo / hi: min and max corner of the cube; inv = 1 / d per component.
-RT_HD int rt_node_slab_class(const RtVec3& lo, const RtVec3& hi, const RtVec3& e, const RtVec3& inv, float T) {
-  const float x0 = (lo.x - e.x) * inv.x, x1 = (hi.x - e.x) * inv.x;
-  const float y0 = (lo.y - e.y) * inv.y, y1 = (hi.y - e.y) * inv.y;
-  const float z0 = (lo.z - e.z) * inv.z, z1 = (hi.z - e.z) * inv.z;
-  const float nx = fminf(x0, x1), fx = fmaxf(x0, x1), ny = fminf(y0, y1), fy = fmaxf(y0, y1), nz = fminf(z0, z1), fz = fmaxf(z0, z1);
+// lo / hi: min and max corner of the cube; inv = 1 / d per component; zx, zy, zz: that component of d is zero;
+// any_zero: some lane of the wave has a zero component (wave-uniform: skips the extra work otherwise).
+RT_HD int rt_node_slab_class(const RtVec3& lo, const RtVec3& hi, const RtVec3& e, const RtVec3& inv, float T, bool any_zero,
+                             bool zx, bool zy, bool zz) {
+  float x0 = (lo.x - e.x) * inv.x, x1 = (hi.x - e.x) * inv.x;
+  float y0 = (lo.y - e.y) * inv.y, y1 = (hi.y - e.y) * inv.y;
+  float z0 = (lo.z - e.z) * inv.z, z1 = (hi.z - e.z) * inv.z;
+  float nx = fminf(x0, x1), fx = fmaxf(x0, x1), ny = fminf(y0, y1), fy = fmaxf(y0, y1), nz = fminf(z0, z1), fz = fmaxf(z0, z1);
+  bool z_rej = false, z_und = false;
+  if (any_zero) {
+    const float side = hi.x - lo.x;
+    const float NINF = -__builtin_inff(), PINF = __builtin_inff();
+    if (zx) { const int c = rt_zero_axis(lo.x, hi.x, e.x, side); z_rej |= c < 0; z_und |= c == 0; nx = NINF; fx = PINF; x0 = 0.f; x1 = 0.f; }
+    if (zy) { const int c = rt_zero_axis(lo.y, hi.y, e.y, side); z_rej |= c < 0; z_und |= c == 0; ny = NINF; fy = PINF; y0 = 0.f; y1 = 0.f; }
+    if (zz) { const int c = rt_zero_axis(lo.z, hi.z, e.z, side); z_rej |= c < 0; z_und |= c == 0; nz = NINF; fz = PINF; z0 = 0.f; z1 = 0.f; }
+  }
   const float tN = rt_max3(nx, ny, nz), tN2 = rt_med3(nx, ny, nz);
   const float tF = rt_min3(fx, fy, fz), tF2 = rt_med3(fx, fy, fz);
   // every in-plane comparison of the reference carries the magnitude of an offset measured from a corner of the
@@ -323,8 +353,38 @@ RT_HD int rt_node_slab_class(const RtVec3& lo, const RtVec3& hi, const RtVec3& e
   const float a = rt_min3(T - tc, gap, span);
   const bool acc = (a > E) & (tc > E);
   const float r = rt_max3(-span, -tF, tc - T);
-  const bool rej = r > E;
-  return acc ? 1 : (rej ? -1 : 0);
+  const bool rej = (r > E) | z_rej;
+  return rej ? -1 : ((acc & !z_und) ? 1 : 0);
+}
+
+// The same classification when no direction component is zero, on the interleaved (lo, hi) layout of the wave
+// kernel's node records.  acc / rej equal "class > 0" / "class < 0" of rt_node_slab_class; neither = undecided.
+// (tc - T = -(T - tc) exactly, and max3(-a,-b,-c) > E <=> min3(a,b,c) < -E; a NaN can only come from an infinite
+// plane distance, which makes E infinite and both comparisons false.)
+RT_HD void rt_node_slab_fast(float lox, float hix, float loy, float hiy, float loz, float hiz, const RtVec3& e, const RtVec3& inv,
+                             float T, bool& acc, bool& rej) {
+  const float x0 = (lox - e.x) * inv.x, x1 = (hix - e.x) * inv.x;
+  const float y0 = (loy - e.y) * inv.y, y1 = (hiy - e.y) * inv.y;
+  const float z0 = (loz - e.z) * inv.z, z1 = (hiz - e.z) * inv.z;
+  const float nx = fminf(x0, x1), fx = fmaxf(x0, x1), ny = fminf(y0, y1), fy = fmaxf(y0, y1), nz = fminf(z0, z1), fz = fmaxf(z0, z1);
+  const float tN = rt_max3(nx, ny, nz), tN2 = rt_med3(nx, ny, nz);
+  const float tF = rt_min3(fx, fy, fz), tF2 = rt_med3(fx, fy, fz);
+  const float M = fmaxf(rt_max3(fabsf(x0), fabsf(x1), fabsf(y0)), rt_max3(fabsf(y1), fabsf(z0), fabsf(z1)));
+  const float E = RT_SLAB_EPS * (M + T);
+  const float span = tF - tN;
+  const bool front = tN > 0.f;
+  const float tc = front ? tN : tF;
+  const float gap = front ? tN - tN2 : tF2 - tF;
+  const float x = T - tc;
+  acc = fminf(rt_min3(x, gap, span), tc) > E;
+  rej = rt_min3(span, tF, x) < -E;
+}
+
+// Same classification as two predicates (accepted / undecided), the form the wave kernel ballots.
+RT_HD void rt_node_slab_class2(const RtVec3& lo, const RtVec3& hi, const RtVec3& e, const RtVec3& inv, float T, bool any_zero,
+                               unsigned zmask, bool& accepted, bool& undecided) {
+  const int c = rt_node_slab_class(lo, hi, e, inv, T, any_zero, (zmask & 1u) != 0u, (zmask & 2u) != 0u, (zmask & 4u) != 0u);
+  accepted = c > 0; undecided = c == 0;
 }
 
 #endif

@@ -33,8 +33,17 @@ static bool check_node(const RtVec3& ini, const RtVec3& end, const RtVec3& e, co
   {   // the slab classification may abstain, never contradict
     const RtVec3 lo = {ini.x, ini.y, end.z}, hi = {end.x, end.y, ini.z};
     const RtVec3 inv = {1.f / d.x, 1.f / d.y, 1.f / d.z};
-    const int cls = rt_node_slab_class(lo, hi, e, inv, T);
+    const bool zx = d.x == 0.f, zy = d.y == 0.f, zz = d.z == 0.f;
+    const int cls = rt_node_slab_class(lo, hi, e, inv, T, zx | zy | zz, zx, zy, zz);
     if (cls == 0) n_amb++;
+    if (!(zx | zy | zz)) {
+      bool fa, fr;
+      rt_node_slab_fast(lo.x, hi.x, lo.y, hi.y, lo.z, hi.z, e, inv, T, fa, fr);
+      if (fa != (cls > 0) || fr != (cls < 0)) {
+        if (n_bad < 10) printf("SLAB FAST/GENERAL DIFFER cls %d fast %d %d\n", cls, (int)fa, (int)fr);
+        n_bad++;
+      }
+    }
     if ((cls > 0 && !lit) || (cls < 0 && lit)) {
       if (n_bad < 10) printf("SLAB CONTRADICTION cls %d lit %d ini %.9g %.9g %.9g end %.9g %.9g %.9g e %.9g %.9g %.9g d %.9g %.9g %.9g T %.9g\n", cls, lit,
              ini.x, ini.y, ini.z, end.x, end.y, end.z, e.x, e.y, e.z, d.x, d.y, d.z, T);
