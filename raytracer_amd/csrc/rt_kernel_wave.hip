@@ -48,7 +48,6 @@ __device__ __forceinline__ void trace_wave(const float4* __restrict__ nodes, con
   uint64_t live = __builtin_amdgcn_ballot_w64(want);
   if (!live) return;
   if (COUNT) tl.w[0]++;
-  RtTFloat tf = rt_t_float(rt_ray_const(d), hit.t);
   const RtVec3 inv = {1.f / d.x, 1.f / d.y, 1.f / d.z};   // only feeds the conservative classification
   const unsigned zmask = (d.x == 0.f ? 1u : 0u) | (d.y == 0.f ? 2u : 0u) | (d.z == 0.f ? 4u : 0u);
   const bool any_zero = (__builtin_amdgcn_ballot_w64(zmask != 0u) & live) != 0ull;
@@ -80,7 +79,7 @@ __device__ __forceinline__ void trace_wave(const float4* __restrict__ nodes, con
       rem &= rem - 1u;
       const float4 na = nx_a, nb = nx_b;
       if (rem != 0u) { const uint32_t i = top_first + (uint32_t)__builtin_ctz(rem); nx_a = nodes[2 * i]; nx_b = nodes[2 * i + 1]; }
-      if (COUNT) { tl.w[1]++; if ((mine_m >> lane) & 1ull) tl.node++; }
+      if (COUNT) { if (uni(__float_as_uint(nb.w)) != 0u) tl.w[1]++; if ((mine_m >> lane) & 1ull) tl.node++; }   // w[1]: iterations the plain variant also makes
       // conservative slab classification first; the exact test only where some lane is within rounding of a boundary
       uint64_t acc_m, und_m;
       if (!any_zero) {
@@ -104,13 +103,18 @@ __device__ __forceinline__ void trace_wave(const float4* __restrict__ nodes, con
       }
       if (und_m) {
         if (COUNT) tl.w[2]++;
+        // Rare path (about 1 % of the node tests): the per-ray constants of the exact test are derived here, from
+        // values the compiler cannot hoist, instead of occupying registers across the whole walk.
+        RtVec3 dd = d, ee = e; float T = hit.t;
+        asm volatile("" : "+v"(dd.x), "+v"(dd.y), "+v"(dd.z), "+v"(ee.x), "+v"(ee.y), "+v"(ee.z), "+v"(T));
+        const RtRayConst rc = rt_ray_const(dd);
         const RtVec3 ini = {na.x, na.z, nb.y}, end = {na.y, na.w, nb.x};
-        const float S = rt_node_score(ini, end, e, d, rt_ray_const(d), tf);
+        const float S = rt_node_score(ini, end, ee, dd, rc, rt_t_float(rc, T));
         uint64_t pos_m = __builtin_amdgcn_ballot_w64(S > 0.f);
         const uint64_t tie_m = __builtin_amdgcn_ballot_w64(S == 0.f) & und_m;
         if (tie_m) {   // a boundary case: settle it with the compare form
           if (COUNT) tl.w[3]++;
-          const bool ex = rt_node_accept_exact(ini, end, e, d, rt_ray_const(d), rt_t_const(rt_ray_const(d), hit.t));
+          const bool ex = rt_node_accept_exact(ini, end, ee, dd, rc, rt_t_const(rc, T));
           pos_m = (pos_m & ~tie_m) | (__builtin_amdgcn_ballot_w64(ex) & tie_m);
         }
         acc_m |= pos_m & und_m;
@@ -158,8 +162,8 @@ __device__ __forceinline__ void trace_wave(const float4* __restrict__ nodes, con
         const unsigned s = rt_bits(n.det) & 0x80000000u;
         const float ad = fabsf(n.det);
         const float nbs = rt_from_bits(rt_bits(n.nb) ^ s);
-        // 0 <= beta <= 1 with det != 0  <=>  min(nbs, |det| - nbs) >= 0 and |det| > 0
-        uint64_t pass_m = __builtin_amdgcn_ballot_w64(ad > 0.f) & __builtin_amdgcn_ballot_w64(fminf(nbs, ad - nbs) >= 0.f) & acc_m;
+        // 0 <= beta <= 1  <=>  0 <= nbs <= |det|   (det == 0 cannot survive stage 3: 0 < nts <= 0)
+        uint64_t pass_m = __builtin_amdgcn_ballot_w64(nbs >= 0.f) & __builtin_amdgcn_ballot_w64(nbs <= ad) & acc_m;
 #ifdef RT_ABL_TRI2
         {   // ablation: stage 1 a second time
           RtVec3 e_ = e; asm volatile("" : "+v"(e_.x), "+v"(e_.y), "+v"(e_.z));
@@ -178,7 +182,7 @@ __device__ __forceinline__ void trace_wave(const float4* __restrict__ nodes, con
         const float m21 = -e1.x * c2.y + e1.y * c2.x;
         n.ng = m01 * b.x + m11 * b.y + m21 * b.z;
         const float ngs = rt_from_bits(rt_bits(n.ng) ^ s);
-        pass_m &= __builtin_amdgcn_ballot_w64(fminf(ngs, ad - ngs) >= 0.f);
+        pass_m &= __builtin_amdgcn_ballot_w64(ngs >= 0.f) & __builtin_amdgcn_ballot_w64(ngs <= ad);
         if (!pass_m) continue;
         if (COUNT) tl.w[6]++;
         // stage 3: t numerator; t > 0, and t clearly beyond the closest hit is rejected without dividing
@@ -197,11 +201,7 @@ __device__ __forceinline__ void trace_wave(const float4* __restrict__ nodes, con
         changed_m |= pass_m;   // a superset of the lanes whose t changed is enough: their bounds are simply refreshed
       }
       if (changed_m) {
-        bool done = false;
-        if ((changed_m >> lane) & 1ull) {
-          tf = rt_t_float(rt_ray_const(d), hit.t);
-          done = stop_t >= 0.f && hit.t < stop_t;
-        }
+        const bool done = stop_t >= 0.f && hit.t < stop_t;
         live &= ~__builtin_amdgcn_ballot_w64(done);
         if (!live) return;
       }
@@ -232,36 +232,45 @@ enum { PH_CLOSEST = 0, PH_SHADOW = 1, PH_DONE = 2, PH_SHADE = 3 };
 template <bool BOUNCE>
 struct ShadeState {
   RtVec3 P, N, view;                 // hit point, shading normal, direction of the ray being shaded
-  float colr[3], color[3];           // colour of the ray being shaded, colour of the pixel so far
+  RtVec3 colr, color;                // colour of the ray being shaded, colour of the pixel so far
   float hit_t;                       // distance of the hit being shaded (Beer attenuation)
   int32_t mfirst, mcount, mi, li;    // material list of the hit primitive, (material, light) cursor
   uint32_t vis_known, vis_occluded;  // per light (first 32): shadow test already traced for this hit point
-  RtVec3 att; float level[RT_MAX_LEVELS]; int32_t nlevel, depth;   // BOUNCE only
+  RtVec3 att; float level0, level1, level2; int32_t nlevel, depth;   // BOUNCE only (no arrays: the state must stay in registers)
+  __device__ __forceinline__ float level_at(int i) const {
+    float a = level0, b = level1, c = level2;
+    asm volatile("" : "+v"(a), "+v"(b), "+v"(c));   // keeps this a select of values: a select of addresses would pin the struct in scratch memory
+    return i == 0 ? a : (i == 1 ? b : c);
+  }
+  __device__ __forceinline__ void set_level(int i, float v) { level0 = i == 0 ? v : level0; level1 = i == 1 ? v : level1; level2 = i == 2 ? v : level2; }
   static constexpr int WORDS = BOUNCE ? 30 : 22;
 };
 
+// One statement per word (no temporary array: the state has to stay in registers on both sides).
+#define RT_SHADE_FLOATS(X) X(0, P.x) X(1, P.y) X(2, P.z) X(3, N.x) X(4, N.y) X(5, N.z) X(6, view.x) X(7, view.y) X(8, view.z) \
+  X(9, colr.x) X(10, colr.y) X(11, colr.z) X(12, color.x) X(13, color.y) X(14, color.z) X(15, hit_t)
+#define RT_SHADE_INTS(X) X(16, mfirst) X(17, mcount) X(18, mi) X(19, li) X(20, vis_known) X(21, vis_occluded)
+#define RT_SHADE_BOUNCE_FLOATS(X) X(22, att.x) X(23, att.y) X(24, att.z) X(25, level0) X(26, level1) X(27, level2)
+#define RT_SHADE_BOUNCE_INTS(X) X(28, nlevel) X(29, depth)
 template <bool BOUNCE>
 __device__ __forceinline__ void park(const ShadeState<BOUNCE>& s, float* lds) {
-  const float w[30] = {s.P.x, s.P.y, s.P.z, s.N.x, s.N.y, s.N.z, s.view.x, s.view.y, s.view.z, s.colr[0], s.colr[1], s.colr[2],
-                       s.color[0], s.color[1], s.color[2], s.hit_t, __int_as_float(s.mfirst), __int_as_float(s.mcount),
-                       __int_as_float(s.mi), __int_as_float(s.li), __uint_as_float(s.vis_known), __uint_as_float(s.vis_occluded),
-                       s.att.x, s.att.y, s.att.z, s.level[0], s.level[1], s.level[2], __int_as_float(s.nlevel), __int_as_float(s.depth)};
-#pragma unroll
-  for (int k = 0; k < ShadeState<BOUNCE>::WORDS; k++) lds[k * RT_BLOCK] = w[k];
+  uint32_t* ldu = (uint32_t*)lds;
+#define PUT_F(k, f) lds[(k) * RT_BLOCK] = s.f;
+#define PUT_I(k, f) ldu[(k) * RT_BLOCK] = (uint32_t)s.f;
+  RT_SHADE_FLOATS(PUT_F) RT_SHADE_INTS(PUT_I)
+  if (BOUNCE) { RT_SHADE_BOUNCE_FLOATS(PUT_F) RT_SHADE_BOUNCE_INTS(PUT_I) }
+#undef PUT_F
+#undef PUT_I
 }
 template <bool BOUNCE>
 __device__ __forceinline__ void unpark(ShadeState<BOUNCE>& s, const float* lds) {
-  float w[30];
-#pragma unroll
-  for (int k = 0; k < 30; k++) w[k] = k < ShadeState<BOUNCE>::WORDS ? lds[k * RT_BLOCK] : 0.f;
-  s.P = {w[0], w[1], w[2]}; s.N = {w[3], w[4], w[5]}; s.view = {w[6], w[7], w[8]};
-  s.colr[0] = w[9]; s.colr[1] = w[10]; s.colr[2] = w[11]; s.color[0] = w[12]; s.color[1] = w[13]; s.color[2] = w[14];
-  s.hit_t = w[15]; s.mfirst = __float_as_int(w[16]); s.mcount = __float_as_int(w[17]); s.mi = __float_as_int(w[18]);
-  s.li = __float_as_int(w[19]); s.vis_known = __float_as_uint(w[20]); s.vis_occluded = __float_as_uint(w[21]);
-  if (BOUNCE) {
-    s.att = {w[22], w[23], w[24]}; s.level[0] = w[25]; s.level[1] = w[26]; s.level[2] = w[27];
-    s.nlevel = __float_as_int(w[28]); s.depth = __float_as_int(w[29]);
-  }
+  const uint32_t* ldu = (const uint32_t*)lds;
+#define GET_F(k, f) s.f = lds[(k) * RT_BLOCK];
+#define GET_I(k, f) s.f = (decltype(s.f))ldu[(k) * RT_BLOCK];
+  RT_SHADE_FLOATS(GET_F) RT_SHADE_INTS(GET_I)
+  if (BOUNCE) { RT_SHADE_BOUNCE_FLOATS(GET_F) RT_SHADE_BOUNCE_INTS(GET_I) }
+#undef GET_F
+#undef GET_I
 }
 
 template <bool BOUNCE, bool COUNT>
@@ -309,9 +318,9 @@ __global__ __launch_bounds__(RT_BLOCK, RT_WAVES_PER_SIMD) void render_wave(
   // ---- shading state (parked during traversal) and the pixel's ray stack (scratch, BOUNCE only) --------
   ShadeState<BOUNCE> sh;
   sh.P = {0, 0, 0}; sh.N = {0, 0, 1}; sh.view = tr_d;
-  for (int k = 0; k < 3; k++) { sh.colr[k] = 0.f; sh.color[k] = 0.f; sh.level[k] = 0.f; }
+  sh.colr = {0.f, 0.f, 0.f}; sh.color = {0.f, 0.f, 0.f}; sh.level1 = 0.f; sh.level2 = 0.f;
   sh.hit_t = RT_INF; sh.mfirst = 0; sh.mcount = 0; sh.mi = 0; sh.li = 0; sh.vis_known = 0; sh.vis_occluded = 0;
-  sh.att = {1.f, 1.f, 1.f}; sh.level[0] = c.scene_refr; sh.nlevel = 0; sh.depth = 0;
+  sh.att = {1.f, 1.f, 1.f}; sh.level0 = c.scene_refr; sh.nlevel = 0; sh.depth = 0;
   BounceRay rstack[BOUNCE ? RT_RAY_STACK : 1];
   int rsp = 0;
 
@@ -336,10 +345,10 @@ __global__ __launch_bounds__(RT_BLOCK, RT_WAVES_PER_SIMD) void render_wave(
         if (ids) ids[p] = h.prim;
         if (ts) ts[p] = h.t;
       }
-      sh.colr[0] = sh.colr[1] = sh.colr[2] = 0.f;
+      sh.colr = {0.f, 0.f, 0.f};
       sh.mi = 0; sh.li = 0; sh.vis_known = 0; sh.vis_occluded = 0; sh.hit_t = h.t; sh.view = tr_d;
       if (h.prim == -1) {
-        sh.colr[0] = c.bg[0]; sh.colr[1] = c.bg[1]; sh.colr[2] = c.bg[2];   // ray.cu:86
+        sh.colr = {c.bg[0], c.bg[1], c.bg[2]};   // ray.cu:86
         sh.mcount = 0;
       } else {
         surface(S, tr_e, tr_d, h, sh.P, sh.N);
@@ -356,13 +365,13 @@ __global__ __launch_bounds__(RT_BLOCK, RT_WAVES_PER_SIMD) void render_wave(
       phase = PH_SHADE;
       while (phase == PH_SHADE) {
         if (sh.mi >= sh.mcount) {   // every material of the hit handled: camera.cu:110-111, then next ray of the pixel
-          sh.color[0] = sh.color[0] + sh.att.x * sh.colr[0];
-          sh.color[1] = sh.color[1] + sh.att.y * sh.colr[1];
-          sh.color[2] = sh.color[2] + sh.att.z * sh.colr[2];
+          sh.color.x = sh.color.x + sh.att.x * sh.colr.x;
+          sh.color.y = sh.color.y + sh.att.y * sh.colr.y;
+          sh.color.z = sh.color.z + sh.att.z * sh.colr.z;
           if (BOUNCE && rsp > 0) {
             const BounceRay& r = rstack[--rsp];
             tr_e = r.eye; tr_d = r.dir; sh.att = r.att;
-            for (int k = 0; k < 3; k++) sh.level[k] = r.level[k];
+            sh.level0 = r.level[0]; sh.level1 = r.level[1]; sh.level2 = r.level[2];
             sh.nlevel = r.nlevel; sh.depth = r.depth;
             phase = PH_CLOSEST; tl.rays++;
           } else phase = PH_DONE;
@@ -375,7 +384,9 @@ __global__ __launch_bounds__(RT_BLOCK, RT_WAVES_PER_SIMD) void render_wave(
           if (li >= n_lights) { sh.mi++; sh.li = 0; continue; }
           const RtLight L = lights[li];
           if (L.type == RT_AMBIENT) {
-            if (M.type == RT_LAMBERT) for (int k = 0; k < 3; k++) sh.colr[k] = sh.colr[k] + M.col[k] * L.col[k];
+            if (M.type == RT_LAMBERT) {
+              sh.colr.x = sh.colr.x + M.col[0] * L.col[0]; sh.colr.y = sh.colr.y + M.col[1] * L.col[1]; sh.colr.z = sh.colr.z + M.col[2] * L.col[2];
+            }
             sh.li++; continue;
           }
           RtVec3 l; float ldist;
@@ -408,7 +419,9 @@ __global__ __launch_bounds__(RT_BLOCK, RT_WAVES_PER_SIMD) void render_wave(
             const float nh = rt_dot(N, hv);
             w = powf(nh > 0.f ? nh : 0.f, M.param);
           }
-          for (int k = 0; k < 3; k++) sh.colr[k] = sh.colr[k] + (M.col[k] * L.col[k]) * w;
+          sh.colr.x = sh.colr.x + (M.col[0] * L.col[0]) * w;
+          sh.colr.y = sh.colr.y + (M.col[1] * L.col[1]) * w;
+          sh.colr.z = sh.colr.z + (M.col[2] * L.col[2]) * w;
           sh.li++;
         } else {
           if (BOUNCE && sh.depth < c.max_depth) {
@@ -420,11 +433,11 @@ __global__ __launch_bounds__(RT_BLOCK, RT_WAVES_PER_SIMD) void render_wave(
                 BounceRay& r = rstack[rsp++];
                 r.eye = {P.x + rl.x * RT_EPS, P.y + rl.y * RT_EPS, P.z + rl.z * RT_EPS}; r.dir = rl;
                 r.att = {M.col[0] * sh.att.x, M.col[1] * sh.att.y, M.col[2] * sh.att.z};
-                for (int k = 0; k < 3; k++) r.level[k] = sh.level[k];
+                r.level[0] = sh.level0; r.level[1] = sh.level1; r.level[2] = sh.level2;
                 r.nlevel = sh.nlevel; r.depth = sh.depth + 1;
               } else atomicAdd(&counters[C_UB_STACK], 1ull);
             } else {   // RT_DIELECTRIC, material.cu:36-99
-              const float refr = sh.level[sh.nlevel];
+              const float refr = sh.level_at(sh.nlevel);
               const RtVec3 rlsP = {P.x + N.x * RT_EPS, P.y + N.y * RT_EPS, P.z + N.z * RT_EPS};
               const float q = (refr - M.param) / (refr + M.param);
               const float R0 = q * q;
@@ -448,7 +461,7 @@ __global__ __launch_bounds__(RT_BLOCK, RT_WAVES_PER_SIMD) void render_wave(
                 if (entering) {
                   nl = sh.nlevel + 1;
                   if (nl > 2) { nl = 2; atomicAdd(&counters[C_UB_OVER], 1ull); }
-                  sh.level[nl] = M.param;
+                  sh.set_level(nl, M.param);
                 } else {
                   nl = sh.nlevel - 1;
                   if (nl < 0) { nl = 0; atomicAdd(&counters[C_UB_LEAVE], 1ull); }
@@ -457,7 +470,7 @@ __global__ __launch_bounds__(RT_BLOCK, RT_WAVES_PER_SIMD) void render_wave(
                   BounceRay& r = rstack[rsp++];
                   r.eye = {P.x + rf.x * RT_EPS, P.y + rf.y * RT_EPS, P.z + rf.z * RT_EPS}; r.dir = rf;
                   r.att = {attf[0], attf[1], attf[2]};
-                  for (int k = 0; k < 3; k++) r.level[k] = sh.level[k];
+                  r.level[0] = sh.level0; r.level[1] = sh.level1; r.level[2] = sh.level2;
                   r.nlevel = nl; r.depth = sh.depth + 1;
                 } else atomicAdd(&counters[C_UB_STACK], 1ull);
                 for (int k = 0; k < 3; k++) attl[k] = attl[k] * fresnel;
@@ -465,7 +478,7 @@ __global__ __launch_bounds__(RT_BLOCK, RT_WAVES_PER_SIMD) void render_wave(
               if (rsp < RT_RAY_STACK) {
                 BounceRay& r = rstack[rsp++];
                 r.eye = rlsP; r.dir = rl; r.att = {attl[0], attl[1], attl[2]};
-                for (int k = 0; k < 3; k++) r.level[k] = sh.level[k];
+                r.level[0] = sh.level0; r.level[1] = sh.level1; r.level[2] = sh.level2;
                 r.nlevel = sh.nlevel; r.depth = sh.depth + 1;
               } else atomicAdd(&counters[C_UB_STACK], 1ull);
             }
@@ -481,7 +494,8 @@ __global__ __launch_bounds__(RT_BLOCK, RT_WAVES_PER_SIMD) void render_wave(
   // dwords instead of 192 single bytes (each byte store is its own partial write to memory).
   uint8_t q[3];
   for (int k = 0; k < 3; k++) {
-    const float v = (sh.color[k] < 1.f ? sh.color[k] : 1.f) * 255.f;
+    const float ck = k == 0 ? sh.color.x : (k == 1 ? sh.color.y : sh.color.z);
+    const float v = (ck < 1.f ? ck : 1.f) * 255.f;
     q[k] = v < 0.f ? (uint8_t)0 : (uint8_t)(int)v;
   }
   if (valid) tl.rays++;   // the primary ray

@@ -55,6 +55,9 @@ __device__ __forceinline__ RtVec3 ld3(const float* p) { return {p[0], p[1], p[2]
 // Hit point and shading normal of the accepted primitive (triangle.cu:141-147, spheres.cu:92-93).
 __device__ __forceinline__ void surface(const RtDeviceView& S, const RtVec3& eye, const RtVec3& dir, const Hit& h,
                                         RtVec3& P, RtVec3& N) {
+  // Results are formed in locals and written once at the end: stores through the references from both arms get
+  // merged by the optimiser into a store through a selected pointer, which pins the caller's state in scratch memory.
+  float px, py, pz, nx, ny, nz;
   if (h.prim >= 0) {
     const float4 g0 = S.tri_geom[3 * h.prim];
     const float4 s0 = S.tri_shade[4 * h.prim], s1 = S.tri_shade[4 * h.prim + 1], s2 = S.tri_shade[4 * h.prim + 2],
@@ -62,14 +65,17 @@ __device__ __forceinline__ void surface(const RtDeviceView& S, const RtVec3& eye
     const float alp = 1 - h.bet - h.gam, bet = h.bet, gam = h.gam;
     const RtVec3 v0 = {g0.x, g0.y, g0.z}, v1 = {s0.x, s0.y, s0.z}, v2 = {s0.w, s1.x, s1.y};
     const RtVec3 n0 = {s1.z, s1.w, s2.x}, n1 = {s2.y, s2.z, s2.w}, n2 = {s3.x, s3.y, s3.z};
-    N = {(n0.x * alp + n1.x * bet) + n2.x * gam, (n0.y * alp + n1.y * bet) + n2.y * gam, (n0.z * alp + n1.z * bet) + n2.z * gam};
-    N = rt_normalized(N);
-    P = {(v0.x * alp + v1.x * bet) + v2.x * gam, (v0.y * alp + v1.y * bet) + v2.y * gam, (v0.z * alp + v1.z * bet) + v2.z * gam};
+    const RtVec3 n = rt_normalized({(n0.x * alp + n1.x * bet) + n2.x * gam, (n0.y * alp + n1.y * bet) + n2.y * gam,
+                                    (n0.z * alp + n1.z * bet) + n2.z * gam});
+    nx = n.x; ny = n.y; nz = n.z;
+    px = (v0.x * alp + v1.x * bet) + v2.x * gam; py = (v0.y * alp + v1.y * bet) + v2.y * gam; pz = (v0.z * alp + v1.z * bet) + v2.z * gam;
   } else {
     const RtSphere& sp = S.spheres[-2 - h.prim];
-    P = {eye.x + dir.x * h.t, eye.y + dir.y * h.t, eye.z + dir.z * h.t};
-    N = rt_normalized({P.x - sp.c[0], P.y - sp.c[1], P.z - sp.c[2]});
+    px = eye.x + dir.x * h.t; py = eye.y + dir.y * h.t; pz = eye.z + dir.z * h.t;
+    const RtVec3 n = rt_normalized({px - sp.c[0], py - sp.c[1], pz - sp.c[2]});
+    nx = n.x; ny = n.y; nz = n.z;
   }
+  P.x = px; P.y = py; P.z = pz; N.x = nx; N.y = ny; N.z = nz;
 }
 
 // vector.cu:147-156

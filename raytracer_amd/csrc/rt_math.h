@@ -369,7 +369,7 @@ RT_HD void rt_node_slab_fast(float lox, float hix, float loy, float hiy, float l
   const float nx = fminf(x0, x1), fx = fmaxf(x0, x1), ny = fminf(y0, y1), fy = fmaxf(y0, y1), nz = fminf(z0, z1), fz = fmaxf(z0, z1);
   const float tN = rt_max3(nx, ny, nz), tN2 = rt_med3(nx, ny, nz);
   const float tF = rt_min3(fx, fy, fz), tF2 = rt_med3(fx, fy, fz);
-  const float M = fmaxf(rt_max3(fabsf(x0), fabsf(x1), fabsf(y0)), rt_max3(fabsf(y1), fabsf(z0), fabsf(z1)));
+  const float M = fmaxf(rt_max3(fx, fy, fz), -rt_min3(nx, ny, nz));   // = max |t| over the six planes, as near <= far per axis
   const float E = RT_SLAB_EPS * (M + T);
   const float span = tF - tN;
   const bool front = tN > 0.f;
