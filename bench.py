@@ -48,6 +48,21 @@ def parse_args():
     return ap.parse_args()
 
 
+def measured_traffic(version):
+    """HBM bytes per launch from the committed rocprofv3 counter passes (profiles/r*_hbm_traffic.json), if they
+    were taken with this very library version; the counters cannot be read from inside the benchmark."""
+    import glob
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_hbm_traffic.json")), reverse=True):
+        try:
+            with open(path) as f:
+                j = json.load(f)
+        except (OSError, ValueError):
+            continue
+        if j.get("library") == version:
+            return j.get("traffic_bytes_per_launch")
+    return None
+
+
 def cpu_baseline(args, threads):
     """Time the CPU oracle on every k-th 16-row band of the same frame (a bounded, representative sample)."""
     from oracle_api import OracleScene
@@ -156,7 +171,8 @@ def main():
             byts = ref["node_tests"] * B_NODE + ref["tri_tests"] * B_TRI + ref["rays"] * B_RAY
             ach = flop / world / (kernel_ms * 1e-3) / 1e12     # per launch: this rank's share of the frame
             roofline = {"bound": "valu_fp32", "achieved": ach, "peak": PEAK_FP32_TFLOPS, "unit": "TFLOP/s",
-                        "frac": ach / PEAK_FP32_TFLOPS, "traffic": None,
+                        "frac": ach / PEAK_FP32_TFLOPS,
+                        "traffic": measured_traffic(rt.version()) if (world == 1 and W == 3840 and H == 2160) else None,
                         "kernel": "render_wave", "kernel_ms": kernel_ms, "flop_per_ray": flop / ref["rays"],
                         "algorithmic_GBps": byts / world / (kernel_ms * 1e-3) / 1e9, "hbm_peak_GBps": PEAK_HBM_GBS}
         out = {

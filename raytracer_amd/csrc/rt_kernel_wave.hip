@@ -282,15 +282,25 @@ __global__ __launch_bounds__(RT_BLOCK, RT_WAVES_PER_SIMD) void render_wave(
     uint8_t* __restrict__ rgb, int32_t* __restrict__ ids, float* __restrict__ ts, unsigned long long* __restrict__ counters) {
   __shared__ float parked[ShadeState<BOUNCE>::WORDS * RT_BLOCK];
   __shared__ uint32_t pack[RT_BLOCK / 64][48];
-  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  const int tid = threadIdx.x, lane = tid & 63;
   float* my_park = &parked[tid];
   WaveStack st = {0u, 0u, 0u, 0u};
   const int W = cam.width, H = cam.height;
-  const int col = blockIdx.x * RT_TILE_W + (wave & 1) * 8 + (lane & 7);
-  const int lrow = blockIdx.y * RT_TILE_H + (wave >> 1) * 8 + (lane >> 3);
-  const int row = rows.row0 + (lrow / rows.band_rows) * rows.band_stride + lrow % rows.band_rows;
-  const int orow = rows.compact ? lrow : row;
-  const bool valid = col < W && lrow < rows.n_local && row < H;
+  // Pixel of a thread: wave w of the block owns the 8x8 tile (w & 1, w >> 1) of the block's 16x16 pixels.  The
+  // coordinates are needed at the start, after the primary ray and at the end; they are derived again each time
+  // from an opaque copy of the thread index, so that none of them occupies a register (or a spill slot) in between.
+  struct Pixel { int col, lrow, row, orow; bool valid; };
+  auto pixel_of = [&](int t) {
+    asm volatile("" : "+v"(t));
+    const int w = t >> 6, l = t & 63;
+    Pixel p;
+    p.col = blockIdx.x * RT_TILE_W + (w & 1) * 8 + (l & 7);
+    p.lrow = blockIdx.y * RT_TILE_H + (w >> 1) * 8 + (l >> 3);
+    p.row = rows.row0 + (p.lrow / rows.band_rows) * rows.band_stride + p.lrow % rows.band_rows;
+    p.orow = rows.compact ? p.lrow : p.row;
+    p.valid = p.col < W && p.lrow < rows.n_local && p.row < H;
+    return p;
+  };
   Tally tl = {0, 0, 0, 0, 0, 0, 0, {0, 0, 0, 0, 0, 0, 0, 0}};
   const RtCamera& c = cam;
 
@@ -301,8 +311,11 @@ __global__ __launch_bounds__(RT_BLOCK, RT_WAVES_PER_SIMD) void render_wave(
   // ---- registers that live across the traversal: the ray being traced and a few flags -----------------
   RtVec3 tr_e, tr_d;        // ray being traced
   float tr_stop = -1.f;     // >= 0: shadow ray, length to the light
+  int phase;
   {
-    const int i = col, j = H - 1 - row;   // camera.cu:94,118: j counts from the bottom
+    const Pixel px0 = pixel_of(tid);
+    phase = px0.valid ? PH_CLOSEST : PH_DONE;
+    const int i = px0.col, j = H - 1 - px0.row;   // camera.cu:94,118: j counts from the bottom
     // camera.cu:96-99; (i+0.5) is a double, so product and sum are double before the store to float
     const float ic = (float)((double)c.left + (double)((c.right - c.left) / (float)(unsigned short)W) * ((double)i + 0.5));
     const float jc = (float)((double)c.bottom + (double)((c.top - c.bottom) / (float)(unsigned short)H) * ((double)j + 0.5));
@@ -311,7 +324,6 @@ __global__ __launch_bounds__(RT_BLOCK, RT_WAVES_PER_SIMD) void render_wave(
     tr_d = rt_normalized(d0);
     tr_e = {c.pos[0], c.pos[1], c.pos[2]};
   }
-  int phase = valid ? PH_CLOSEST : PH_DONE;
   bool primary = true;
   int verdict = -1;   // result of the last shadow ray, until consumed
 
@@ -341,9 +353,12 @@ __global__ __launch_bounds__(RT_BLOCK, RT_WAVES_PER_SIMD) void render_wave(
     if (phase == PH_CLOSEST) {
       if (primary) {
         primary = false;
-        const size_t p = (size_t)orow * W + col;
-        if (ids) ids[p] = h.prim;
-        if (ts) ts[p] = h.t;
+        if (ids || ts) {
+          const Pixel px = pixel_of(tid);
+          const size_t p = (size_t)px.orow * W + px.col;
+          if (ids) ids[p] = h.prim;
+          if (ts) ts[p] = h.t;
+        }
       }
       sh.colr = {0.f, 0.f, 0.f};
       sh.mi = 0; sh.li = 0; sh.vis_known = 0; sh.vis_occluded = 0; sh.hit_t = h.t; sh.view = tr_d;
@@ -498,8 +513,10 @@ __global__ __launch_bounds__(RT_BLOCK, RT_WAVES_PER_SIMD) void render_wave(
     const float v = (ck < 1.f ? ck : 1.f) * 255.f;
     q[k] = v < 0.f ? (uint8_t)0 : (uint8_t)(int)v;
   }
-  if (valid) tl.rays++;   // the primary ray
-  const int col0 = blockIdx.x * RT_TILE_W + (wave & 1) * 8, lrow0 = blockIdx.y * RT_TILE_H + (wave >> 1) * 8;
+  const Pixel pxe = pixel_of(tid);
+  const int wave = (pxe.lrow >> 3 & 1) * 2 + (pxe.col >> 3 & 1);   // = tid >> 6
+  if (pxe.valid) tl.rays++;   // the primary ray
+  const int col0 = pxe.col & ~7, lrow0 = pxe.lrow & ~7;   // tile origin (wave-uniform)
   const int last_row = rows.row0 + ((lrow0 + 7) / rows.band_rows) * rows.band_stride + (lrow0 + 7) % rows.band_rows;
   const bool whole = (W & 3) == 0 && col0 + 8 <= W && lrow0 + 8 <= rows.n_local && last_row < H &&
                      (lrow0 / rows.band_rows) == ((lrow0 + 7) / rows.band_rows);   // wave-uniform
@@ -513,8 +530,8 @@ __global__ __launch_bounds__(RT_BLOCK, RT_WAVES_PER_SIMD) void render_wave(
       uint32_t* dst = (uint32_t*)(rgb + ((size_t)(orow0 + r) * W + col0) * 3) + j;
       *dst = pack[wave][r * 6 + j];
     }
-  } else if (valid) {
-    const size_t p = ((size_t)orow * W + col) * 3;
+  } else if (pxe.valid) {
+    const size_t p = ((size_t)pxe.orow * W + pxe.col) * 3;
     rgb[p] = q[0]; rgb[p + 1] = q[1]; rgb[p + 2] = q[2];
   }
 

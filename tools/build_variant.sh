@@ -1,0 +1,14 @@
+#!/bin/bash
+# Builds a variant of the render library with extra compiler flags for the wave kernel:
+#   tools/build_variant.sh NAME [-DFLAG ...]   ->  build/variants/librt_amd_NAME.so   (select it with RT_AMD_LIB)
+set -e
+cd "$(dirname "$0")/.."
+name=$1; shift
+C=raytracer_amd/csrc
+mkdir -p build/variants
+/opt/rocm/bin/hipcc -std=c++17 -O3 -ffp-contract=off -fPIC --offload-arch=gfx950 -Wall -Wno-unused-function -Iinclude "$@" \
+  -c $C/rt_kernel_wave.hip -o build/variants/wave_$name.o
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o build/variants/librt_amd_$name.so \
+  $C/rt_host.o $C/rt_device.o $C/rt_kernel_lane.o build/variants/wave_$name.o
+rm -f build/variants/wave_$name.o
+echo build/variants/librt_amd_$name.so
