@@ -70,7 +70,7 @@ extern "C" int rt_scene_upload(const rt_scene* s, int device, rt_dscene** out) {
 #undef UP
   V.n_spheres = (int32_t)s->spheres.size(); V.n_lights = (int32_t)s->lights.size(); V.has_oct = s->nodes.empty() ? 0 : 1;
   void* c = nullptr;
-  if (hipMalloc(&c, C_COUNT * sizeof(unsigned long long)) != hipSuccess) { rt_dscene_destroy(d); rt_set_error("hipMalloc(counters) failed"); return RT_ERR_DEVICE; }
+  if (hipMalloc(&c, RT_COUNTER_COPIES * RT_COUNTER_STRIDE * sizeof(unsigned long long)) != hipSuccess) { rt_dscene_destroy(d); rt_set_error("hipMalloc(counters) failed"); return RT_ERR_DEVICE; }
   d->allocs.push_back(c); d->d_counters = (unsigned long long*)c;
   *out = d;
   return RT_OK;
@@ -80,14 +80,14 @@ static int launch_render(rt_dscene* d, const RowMap& rows, uint8_t* d_rgb, int32
                          unsigned flags, rt_stats* stats) {
   hipStream_t stream = (hipStream_t)stream_;
   HIP_TRY(hipSetDevice(d->device));
-  HIP_TRY(hipMemsetAsync(d->d_counters, 0, C_COUNT * sizeof(unsigned long long), stream));
+  HIP_TRY(hipMemsetAsync(d->d_counters, 0, RT_COUNTER_COPIES * RT_COUNTER_STRIDE * sizeof(unsigned long long), stream));
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
   const bool timed = (flags & RT_RENDER_TIME) != 0;
   if (timed) { HIP_TRY(hipEventCreate(&ev0)); HIP_TRY(hipEventCreate(&ev1)); HIP_TRY(hipEventRecord(ev0, stream)); }
   if (rows.n_local > 0) {
     const bool bounce = d->info.has_bounce_materials != 0, count = (flags & RT_RENDER_COUNT_TESTS) != 0;
-    if (flags & RT_RENDER_LITERAL) rt_launch_lane_kernel(d->view, rows, bounce, count, d_rgb, d_ids, d_t, d->d_counters, stream);
-    else rt_launch_wave_kernel(d->view, rows, bounce, count, d_rgb, d_ids, d_t, d->d_counters, stream);
+    if (flags & RT_RENDER_LITERAL) rt_launch_lane_kernel(d->view, rows, bounce, count, d_rgb, d_ids, d_t, d->d_counters, stats != nullptr, stream);
+    else rt_launch_wave_kernel(d->view, rows, bounce, count, d_rgb, d_ids, d_t, d->d_counters, stats != nullptr, stream);
     HIP_TRY(hipGetLastError());
   }
   float ms = 0.f;
@@ -97,9 +97,11 @@ static int launch_render(rt_dscene* d, const RowMap& rows, uint8_t* d_rgb, int32
     (void)hipEventDestroy(ev0); (void)hipEventDestroy(ev1);
   }
   if (stats) {
-    unsigned long long h[C_COUNT];
-    HIP_TRY(hipMemcpyAsync(h, d->d_counters, sizeof h, hipMemcpyDeviceToHost, stream));
+    static thread_local unsigned long long hc[RT_COUNTER_COPIES * RT_COUNTER_STRIDE];
+    HIP_TRY(hipMemcpyAsync(hc, d->d_counters, sizeof hc, hipMemcpyDeviceToHost, stream));
     HIP_TRY(hipStreamSynchronize(stream));
+    unsigned long long h[C_COUNT] = {0};
+    for (int c = 0; c < RT_COUNTER_COPIES; c++) for (int k = 0; k < C_COUNT; k++) h[k] += hc[c * RT_COUNTER_STRIDE + k];
     memset(stats, 0, sizeof *stats);
     stats->rays = h[C_RAYS]; stats->shadow_rays = h[C_SHADOW]; stats->node_tests = h[C_NODE]; stats->leaf_visits = h[C_LEAF];
     stats->tri_tests = h[C_TRI]; stats->sphere_tests = h[C_SPH]; stats->ub_leave_level0 = h[C_UB_LEAVE];

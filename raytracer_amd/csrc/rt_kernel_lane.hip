@@ -60,7 +60,8 @@ __device__ __forceinline__ void trace(const RtDeviceView& S, const RtVec3& eye, 
 template <bool BOUNCE, bool COUNT>
 __global__ __launch_bounds__(RT_BLOCK) void render_tiles(const RtDeviceView S, const RowMap rows,
                                                          uint8_t* __restrict__ rgb, int32_t* __restrict__ ids,
-                                                         float* __restrict__ ts, unsigned long long* __restrict__ counters) {
+                                                         float* __restrict__ ts, unsigned long long* __restrict__ counters_all, int tally) {
+  unsigned long long* const counters = counters_all + ((blockIdx.x + blockIdx.y) & (RT_COUNTER_COPIES - 1)) * RT_COUNTER_STRIDE;
   __shared__ uint32_t lds_stack[RT_OCT_STACK][RT_BLOCK];
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
   const int W = S.cam.width, H = S.cam.height;
@@ -214,6 +215,7 @@ __global__ __launch_bounds__(RT_BLOCK) void render_tiles(const RtDeviceView S, c
   }
 
   // work counters: wave reduction, one atomic per wave and counter
+  if (!tally) return;
   uint32_t vals[6] = {tl.rays, tl.shadow, tl.node, tl.leaf, tl.tri, tl.sph};
   const int n_out = COUNT ? 6 : 2;
   for (int k = 0; k < n_out; k++) {
@@ -227,9 +229,9 @@ __global__ __launch_bounds__(RT_BLOCK) void render_tiles(const RtDeviceView S, c
 }  // namespace
 
 void rt_launch_lane_kernel(const RtDeviceView& view, const RowMap& rows, bool bounce, bool count, uint8_t* rgb, int32_t* ids,
-                           float* ts, unsigned long long* counters, hipStream_t stream) {
+                           float* ts, unsigned long long* counters, bool tally, hipStream_t stream) {
   const dim3 grid((view.cam.width + RT_TILE_W - 1) / RT_TILE_W, (rows.n_local + RT_TILE_H - 1) / RT_TILE_H), block(RT_BLOCK);
-#define LAUNCH(B, C) hipLaunchKernelGGL((render_tiles<B, C>), grid, block, 0, stream, view, rows, rgb, ids, ts, counters)
+#define LAUNCH(B, C) hipLaunchKernelGGL((render_tiles<B, C>), grid, block, 0, stream, view, rows, rgb, ids, ts, counters, tally ? 1 : 0)
   if (bounce && count) LAUNCH(true, true);
   else if (bounce) LAUNCH(true, false);
   else if (count) LAUNCH(false, true);

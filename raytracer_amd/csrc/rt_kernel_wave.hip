@@ -279,7 +279,8 @@ __global__ __launch_bounds__(RT_BLOCK, RT_WAVES_PER_SIMD) void render_wave(
     const float4* __restrict__ tri_geom, const float4* __restrict__ tri_shade, const RtSphere* __restrict__ spheres,
     const RtLight* __restrict__ lights, const RtMaterial* __restrict__ materials, const int32_t* __restrict__ mat_index,
     const int32_t* __restrict__ mesh_mat_first, const int32_t* __restrict__ mesh_mat_count, int n_spheres, int n_lights, int has_oct,
-    uint8_t* __restrict__ rgb, int32_t* __restrict__ ids, float* __restrict__ ts, unsigned long long* __restrict__ counters) {
+    uint8_t* __restrict__ rgb, int32_t* __restrict__ ids, float* __restrict__ ts, unsigned long long* __restrict__ counters_all, int tally) {
+  unsigned long long* const counters = counters_all + ((blockIdx.x + blockIdx.y) & (RT_COUNTER_COPIES - 1)) * RT_COUNTER_STRIDE;
   __shared__ float parked[ShadeState<BOUNCE>::WORDS * RT_BLOCK];
   __shared__ uint32_t pack[RT_BLOCK / 64][48];
   const int tid = threadIdx.x, lane = tid & 63;
@@ -536,6 +537,7 @@ __global__ __launch_bounds__(RT_BLOCK, RT_WAVES_PER_SIMD) void render_wave(
   }
 
   // work counters: wave reduction, one atomic per wave and counter
+  if (!tally) return;   // nobody asked for statistics
   const uint32_t vals[7] = {tl.rays, tl.shadow, tl.node, tl.leaf, tl.tri, tl.sph, tl.traced};
   const int slot[7] = {C_RAYS, C_SHADOW, C_NODE, C_LEAF, C_TRI, C_SPH, C_TRACED};
   for (int k = 0; k < 7; k++) {
@@ -550,12 +552,12 @@ __global__ __launch_bounds__(RT_BLOCK, RT_WAVES_PER_SIMD) void render_wave(
 }  // namespace
 
 void rt_launch_wave_kernel(const RtDeviceView& V, const RowMap& rows, bool bounce, bool count, uint8_t* rgb, int32_t* ids,
-                           float* ts, unsigned long long* counters, hipStream_t stream) {
+                           float* ts, unsigned long long* counters, bool tally, hipStream_t stream) {
   const dim3 grid((V.cam.width + RT_TILE_W - 1) / RT_TILE_W, (rows.n_local + RT_TILE_H - 1) / RT_TILE_H), block(RT_BLOCK);
 #define LAUNCH(B, C)                                                                                                             \
   hipLaunchKernelGGL((render_wave<B, C>), grid, block, 0, stream, V.cam, rows, V.wnodes, V.tri_leaf, V.tri_geom, V.tri_shade,     \
                      V.spheres, V.lights, V.materials, V.mat_index, V.mesh_mat_first, V.mesh_mat_count, V.n_spheres, V.n_lights, \
-                     V.has_oct, rgb, ids, ts, counters)
+                     V.has_oct, rgb, ids, ts, counters, tally ? 1 : 0)
   if (bounce && count) LAUNCH(true, true);
   else if (bounce) LAUNCH(true, false);
   else if (count) LAUNCH(false, true);

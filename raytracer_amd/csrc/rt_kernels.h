@@ -38,6 +38,13 @@ enum { C_RAYS = 0, C_SHADOW, C_NODE, C_LEAF, C_TRI, C_SPH, C_UB_LEAVE, C_UB_OVER
        // wave-level iteration counts of the instrumented production kernel (how often each code path runs)
        C_W_TRACE, C_W_NODE, C_W_NODE_EXACT, C_W_NODE_TIE, C_W_TRI, C_W_TRI_S2, C_W_TRI_S3, C_W_TRI_FIN, C_COUNT };
 
+// The counters exist in RT_COUNTER_COPIES copies of RT_COUNTER_STRIDE slots (one 256-byte line each); a workgroup adds to
+// the copy picked by its index, the host adds the copies up.  One shared copy would serialise a quarter of a million
+// same-address atomics per 4K frame in the memory-side atomic unit (measured: ~1.3 ms of a 1.6 ms sphere.json frame).
+#define RT_COUNTER_COPIES 64
+#define RT_COUNTER_STRIDE 32
+static_assert(C_COUNT <= RT_COUNTER_STRIDE, "counter copy too small");
+
 struct Hit {
   float t;
   int32_t prim;    // >=0 triangle, <=-2 sphere (-2 - index), -1 nothing yet
@@ -93,8 +100,8 @@ __device__ __forceinline__ RtVec3 refract_dir(const RtVec3& d, const RtVec3& n, 
 
 // Launchers (one per kernel family); all asynchronous on `stream`.
 void rt_launch_lane_kernel(const RtDeviceView& view, const RowMap& rows, bool bounce, bool count, uint8_t* rgb, int32_t* ids,
-                           float* ts, unsigned long long* counters, hipStream_t stream);
+                           float* ts, unsigned long long* counters, bool tally, hipStream_t stream);
 void rt_launch_wave_kernel(const RtDeviceView& view, const RowMap& rows, bool bounce, bool count, uint8_t* rgb, int32_t* ids,
-                           float* ts, unsigned long long* counters, hipStream_t stream);
+                           float* ts, unsigned long long* counters, bool tally, hipStream_t stream);
 
 #endif

@@ -47,6 +47,10 @@ static void leaf(const Tree& T, int node, Ray& r) {
   }
 }
 
+#include <unordered_map>
+static std::unordered_map<int, unsigned long long> g_tested;   // per trace: lanes that have tested a triangle (mailbox study)
+static double g_skippable = 0, g_total_iter = 0, g_last8 = 0, g_last16 = 0;
+static std::vector<int> g_recent;
 struct Cost { double simt_node = 0, simt_tri = 0, sync_node = 0, sync_tri = 0, lane_node = 0, lane_tri = 0, waves = 0, sync_tri_active = 0, sync_node_active = 0; };
 
 // SIMT replay of up to 64 rays in lockstep.
@@ -85,6 +89,23 @@ static void sync_rec(const Tree& T, int node, std::vector<Ray>& rays, const std:
     if (T.kind[ch] < 0) sync_rec(T, ch, rays, m, C);
     else {
       for (size_t i = 0; i < rays.size(); i++) if (m[i]) leaf(T, ch, rays[i]);
+      {
+        unsigned long long mm = 0; for (size_t i = 0; i < rays.size(); i++) if (m[i]) mm |= 1ull << i;
+        for (int k = 0; k < T.kind[ch]; k++) {
+          int id = T.refs[T.ref_first[ch] + k];
+          unsigned long long& t = g_tested[id];
+          g_total_iter++;
+          if ((mm & ~t) == 0) {
+            g_skippable++;
+            // would a small "recently tested" window have caught it?
+            int pos = -1; for (int q = (int)g_recent.size() - 1, n = 0; q >= 0 && n < 64; q--, n++) if (g_recent[q] == id) { pos = n; break; }
+            if (pos >= 0 && pos < 32) g_last8++;
+            if (pos >= 0 && pos < 64) g_last16++;
+          }
+          t |= mm;
+          g_recent.push_back(id);
+        }
+      }
       C.sync_tri += T.kind[ch]; C.sync_tri_active += (double)T.kind[ch] * cnt;
     }
   }
@@ -120,6 +141,7 @@ int main(int ac, char** av) {
     std::vector<Ray> a = rays, b = rays;
     run_simt(T, a, P); P.waves++;
     std::vector<char> all(rays.size(), 1);
+    g_tested.clear(); g_recent.clear();
     sync_rec(T, 0, b, all, P);
     for (size_t i = 0; i < a.size(); i++) if (a[i].prim != b[i].prim || a[i].t != b[i].t) { printf("MISMATCH simt/sync\n"); return 2; }
     // shadow rays of the hit pixels (no early exit here: full reference traversal)
@@ -142,6 +164,7 @@ int main(int ac, char** av) {
       for (size_t i = 0; i < sh.size(); i++) if (sh[i].alive) { m[i] = 1; anyalive = true; }
       if (!anyalive) continue;
       run_simt(T, sa, S); S.waves++;
+      g_tested.clear(); g_recent.clear();
       sync_rec(T, 0, sb, m, S);
     }
     tiles++;
@@ -151,6 +174,8 @@ int main(int ac, char** av) {
            name, C.waves, C.simt_node / C.waves, C.simt_tri / C.waves, C.sync_node / C.waves, C.sync_tri / C.waves,
            C.lane_node / C.waves / 64, C.lane_tri / C.waves / 64, C.sync_node_active / C.sync_node, C.sync_tri_active / (C.sync_tri > 0 ? C.sync_tri : 1));
   };
+  printf("mailbox study: triangle iterations %.0f, skippable (all active lanes already tested it in this trace) %.0f = %.1f%%, of which within last 32 iterations %.1f%%, last 64 %.1f%%\n",
+         g_total_iter, g_skippable, 100 * g_skippable / g_total_iter, 100 * g_last8 / g_total_iter, 100 * g_last16 / g_total_iter);
   printf("scene %s %dx%d, %d tiles of %dx%d sampled\n", scene, W, H, tiles, tw, th);
   rep("primary", P); rep("shadow-pt", S1); rep("shadow-dir", S2);
   return 0;
