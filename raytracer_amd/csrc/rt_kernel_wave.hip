@@ -223,6 +223,9 @@ __device__ __forceinline__ void trace_wave(const float4* __restrict__ nodes, con
 
 enum { PH_CLOSEST = 0, PH_SHADOW = 1, PH_DONE = 2, PH_SHADE = 3 };
 
+#ifndef RT_WAVES_PER_SIMD_BOUNCE
+#define RT_WAVES_PER_SIMD_BOUNCE 4   // the bounce variant carries more state; at 5 it spills inside the triangle loop
+#endif
 #ifndef RT_WAVES_PER_SIMD
 #define RT_WAVES_PER_SIMD 5
 #endif
@@ -274,7 +277,7 @@ __device__ __forceinline__ void unpark(ShadeState<BOUNCE>& s, const float* lds) 
 }
 
 template <bool BOUNCE, bool COUNT>
-__global__ __launch_bounds__(RT_BLOCK, RT_WAVES_PER_SIMD) void render_wave(
+__global__ __launch_bounds__(RT_BLOCK, BOUNCE ? RT_WAVES_PER_SIMD_BOUNCE : RT_WAVES_PER_SIMD) void render_wave(
     const RtCamera cam, const RowMap rows, const float4* __restrict__ nodes, const float4* __restrict__ tri_leaf,
     const float4* __restrict__ tri_geom, const float4* __restrict__ tri_shade, const RtSphere* __restrict__ spheres,
     const RtLight* __restrict__ lights, const RtMaterial* __restrict__ materials, const int32_t* __restrict__ mat_index,

@@ -20,11 +20,11 @@ def _rgb_close(a, b):
     return frac_ok, int((diff > 0).sum()), int(diff.max())
 
 
-def _check_scene(name, w, h, depth=3):
+def _check_scene(name, w, h, depth=3, base_dir=None):
     path = name if name.endswith(".json") else "scenes/%s.json" % name
-    o = OracleScene(path, w, h, depth)
+    o = OracleScene(path, w, h, depth, base_dir=base_dir)
     orgb, oids, ots, oct_ = o.render(threads=8)
-    ds = rt.DeviceScene(rt.Scene(path, w, h, depth))
+    ds = rt.DeviceScene(rt.Scene(path, w, h, depth, base_dir=base_dir))
     # instrumented variant: full traversals, counts every test
     rgb, ids, ts, st = ds.render_host(flags=rt.RT_RENDER_COUNT_TESTS)
     assert np.array_equal(ids, oids), "primary hit ids differ on %d pixels" % int((ids != oids).sum())
@@ -182,3 +182,12 @@ def test_spot_lights_synthetic_scene(tmp_path):
         q = tmp_path / ("spots_%s.json" % shadows)
         q.write_text(SPOT_SCENE.replace('"enable_shadows": "true"', '"enable_shadows": "%s"' % shadows))
         _check_scene(str(q), 200, 120)
+
+
+@pytest.mark.parametrize("k,w,h", [(3, 256, 256), (5, 320, 180)])
+def test_synthetic_icosphere_scene(tmp_path, k, w, h):
+    # The benchmark's synthetic mesh (20 * 4**k triangles over the large plane), at sizes the oracle renders in seconds.
+    from raytracer_amd.synthetic import write_icosphere_scene
+    path, n = write_icosphere_scene(str(tmp_path), k)
+    assert n == 20 * 4 ** k
+    _check_scene(path, w, h, base_dir=str(tmp_path))
