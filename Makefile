@@ -6,7 +6,7 @@ ARCH     ?= gfx950
 CSRC     := raytracer_amd/csrc
 # -ffp-contract=off everywhere: the reference arithmetic has no fused multiply-adds and the
 # accept/reject decisions of the traversal are compared bit for bit.
-HOSTFLAGS := -std=c++17 -O2 -ffp-contract=off -fPIC -Wall -Wno-unused-function -Iinclude
+HOSTFLAGS := -std=c++17 -O2 -ffp-contract=off -fPIC -pthread -Wall -Wno-unused-function -Iinclude
 HIPFLAGS  := -std=c++17 -O3 -ffp-contract=off -fPIC --offload-arch=$(ARCH) -Wall -Wno-unused-function -Iinclude
 
 LIB := raytracer_amd/librt_amd.so
@@ -23,7 +23,7 @@ $(CSRC)/%.o: $(CSRC)/%.hip $(CSRC)/rt_kernels.h $(CSRC)/rt_internal.h $(CSRC)/rt
 	$(HIPCC) $(HIPFLAGS) -c $< -o $@
 
 $(LIB): $(CSRC)/rt_host.o $(HIPOBJS)
-	$(HIPCC) --offload-arch=$(ARCH) -shared -fPIC -o $@ $^
+	$(HIPCC) --offload-arch=$(ARCH) -shared -fPIC -pthread -o $@ $^
 
 $(RUN): $(CSRC)/run_main.cpp $(LIB) include/rt_amd.h
 	$(CXX) $(HOSTFLAGS) $< -o $@ -Lraytracer_amd -lrt_amd -Wl,-rpath,'$$ORIGIN'

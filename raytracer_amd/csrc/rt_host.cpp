@@ -7,6 +7,7 @@
 // vector/vector.cu:35-63, octtree/octtree.cu:14-20,90-112,162-174, parsing/parsing.cu:21-130,145-473).
 // Build with -ffp-contract=off.
 #include <algorithm>
+#include <atomic>
 #include <chrono>
 #include <cmath>
 #include <cstdio>
@@ -14,6 +15,7 @@
 #include <cstring>
 #include <map>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "rt_internal.h"
@@ -333,32 +335,64 @@ void mesh_rotate(HostMesh& m, const std::vector<float>& r) {      // mesh.cu:28-
 }
 
 // ------------------------------------------------------------------ octree
-// Separating-axis test of triangle.cu:61-105: nine edge x box-normal axes only, projections with
-// the double-accumulating dot, intervals seeded with +-64.
-bool triangle_touches_box(const float* tv, const float* ini, const float* end) {
+// Separating-axis test of triangle.cu:61-105: nine edge x box-normal axes only (the three box axes and the
+// triangle normal are missing, so leaves also hold triangles that merely come close), projections with the
+// double-accumulating dot over the three triangle vertices and the eight box corners, intervals seeded with +-64.
+// Evaluated here with everything that does not depend on the box taken out of it.
+//   * The axis edge x unit_k has a zero k-component and the other two are +-edge components, so a projection
+//     is the double sum of two float products (the third product is +-0 and leaves the sum unchanged).
+//   * The triangle's interval on an axis depends on the triangle only: computed once per triangle.
+//   * Rounding is monotone, so the box interval over the eight corners is attained at the two corners picked
+//     by the signs of the axis components: two projections instead of eight.
+// The decisions are those of the literal form bit for bit (the tests compare the trees with the oracle's, which evaluates it literally).
+struct TriAxes {
+  float a[9], b[9];        // the two non-zero axis components, on coordinates (k+1)%3 and (k+2)%3 of axis 3*k+ei
+  float tmin[9], tmax[9];  // triangle interval, seeded with +-64
+  uint32_t live;           // bit per axis: 0 = degenerate axis, skipped by the reference
+};
+
+inline float proj2(float c1, float a, float c2, float b) {   // dot_dacc restricted to the two live coordinates
+  double s = 0.0;
+  s += (double)(c1 * a);
+  s += (double)(c2 * b);
+  return (float)s;
+}
+
+TriAxes make_tri_axes(const float* tv) {
   const float* v0 = tv; const float* v1 = tv + 3; const float* v2 = tv + 6;
   const float edge[3][3] = {{v1[0] - v0[0], v1[1] - v0[1], v1[2] - v0[2]},
                             {v2[0] - v1[0], v2[1] - v1[1], v2[2] - v1[2]},
                             {v0[0] - v2[0], v0[1] - v2[1], v0[2] - v2[2]}};
   static const float unit[3][3] = {{1, 0, 0}, {0, 1, 0}, {0, 0, 1}};
-  const float corner[8][3] = {{ini[0], ini[1], ini[2]}, {end[0], ini[1], ini[2]}, {ini[0], end[1], ini[2]},
-                              {ini[0], ini[1], end[2]}, {end[0], end[1], ini[2]}, {end[0], ini[1], end[2]},
-                              {ini[0], end[1], end[2]}, {end[0], end[1], end[2]}};
-  for (int bi = 0; bi < 3; bi++) {
-    for (int ei = 0; ei < 3; ei++) {
-      float ax[3]; cross3(ax, edge[ei], unit[bi]);
-      if (!dot_dacc(ax, ax)) continue;
-      float tmin = RT_INF, tmax = -RT_INF, bmin = RT_INF, bmax = -RT_INF;
+  TriAxes T; T.live = 0;
+  for (int bi = 0; bi < 3; bi++) for (int ei = 0; ei < 3; ei++) {
+    const int x = 3 * bi + ei, i1 = (bi + 1) % 3, i2 = (bi + 2) % 3;
+    float ax[3]; cross3(ax, edge[ei], unit[bi]);
+    T.a[x] = ax[i1]; T.b[x] = ax[i2];
+    float tmin = RT_INF, tmax = -RT_INF;
+    if (dot_dacc(ax, ax)) {
+      T.live |= 1u << x;
       for (int j = 0; j < 3; j++) {
         const float pr = dot_dacc(tv + 3 * j, ax);
         tmax = std::max(tmax, pr); tmin = std::min(tmin, pr);
       }
-      for (int c = 0; c < 8; c++) {
-        const float pr = dot_dacc(corner[c], ax);
-        bmax = std::max(bmax, pr); bmin = std::min(bmin, pr);
-      }
-      if (tmax < bmin || tmin > bmax) return false;
     }
+    T.tmin[x] = tmin; T.tmax[x] = tmax;
+  }
+  return T;
+}
+
+inline bool tri_axes_touch_box(const TriAxes& T, const float* ini, const float* end) {
+  for (int x = 0; x < 9; x++) {
+    if (!((T.live >> x) & 1u)) continue;
+    const int bi = x / 3, i1 = (bi + 1) % 3, i2 = (bi + 2) % 3;
+    const float a = T.a[x], b = T.b[x];
+    const float lo1 = std::min(ini[i1], end[i1]), hi1 = std::max(ini[i1], end[i1]);
+    const float lo2 = std::min(ini[i2], end[i2]), hi2 = std::max(ini[i2], end[i2]);
+    // c * a is smallest at lo when a >= 0, at hi otherwise
+    const float bmin = std::min(RT_INF, proj2(a >= 0 ? lo1 : hi1, a, b >= 0 ? lo2 : hi2, b));
+    const float bmax = std::max(-RT_INF, proj2(a >= 0 ? hi1 : lo1, a, b >= 0 ? hi2 : lo2, b));
+    if (T.tmax[x] < bmin || T.tmin[x] > bmax) return false;
   }
   return true;
 }
@@ -369,10 +403,21 @@ bool triangle_touches_box(const float* tv, const float* ini, const float* end) {
 // that set has more than 50 members, because a leaf splits the moment its 51st member arrives and
 // re-inserts its members in order.  Nodes are laid out so the eight children of a branch are
 // consecutive and subtrees follow depth-first order, which is the order rays walk them.
+//
+// Subtrees are independent, so they are built by concurrent tasks into private arrays (indices relative to
+// the subtree) and spliced in depth-first order afterwards: the result does not depend on the number of threads.
 struct TreeBuilder {
   rt_scene& sc;
-  int max_depth = 0;
+  std::vector<TriAxes> axes;
+  std::atomic<int> spare_threads{0};
   explicit TreeBuilder(rt_scene& s) : sc(s) {}
+
+  struct Sub {                       // descendants of one node, in depth-first block order
+    std::vector<RtNode> nodes;       // `first` of branches relative to nodes[0]; `first` of leaves relative to refs[0]
+    std::vector<int32_t> refs;
+    int max_depth = 0;
+    bool too_deep = false;
+  };
 
   static void child_box(const float* ini, const float* end, int c, float* ci, float* ce) {   // octtree.cu:95-111
     for (int k = 0; k < 3; k++) {
@@ -388,45 +433,87 @@ struct TreeBuilder {
   static void set_links(RtNode& n, int32_t first, int32_t count) {
     memcpy(&n.a[3], &first, 4); memcpy(&n.b[3], &count, 4);
   }
+  static void get_links(const RtNode& n, int32_t& first, int32_t& count) {
+    memcpy(&first, &n.a[3], 4); memcpy(&count, &n.b[3], 4);
+  }
 
-  // Node `id` (bounds already set) receives `tris`; depth of the root is 0.
-  void fill(int32_t id, const std::vector<int32_t>& tris, int depth, bool force_branch) {
-    if (depth > max_depth) max_depth = depth;
+  // Fills `self` (bounds already set) and appends its descendants to `out`; depth of the root is 0.
+  void fill(RtNode& self, const std::vector<int32_t>& tris, int depth, bool force_branch, Sub& out) {
+    if (depth > out.max_depth) out.max_depth = depth;
     if (!force_branch && (int)tris.size() <= RT_LEAF_CAP) {
-      set_links(sc.nodes[id], (int32_t)sc.leaf_refs.size(), (int32_t)tris.size());
-      sc.leaf_refs.insert(sc.leaf_refs.end(), tris.begin(), tris.end());
+      set_links(self, (int32_t)out.refs.size(), (int32_t)tris.size());
+      out.refs.insert(out.refs.end(), tris.begin(), tris.end());
       return;
     }
-    if (depth + 1 >= RT_OCT_STACK)
-      throw Fail{RT_ERR_LIMIT, "octree would be deeper than the 20-entry traversal stack (more than 50 triangles meet in one point)"};
-    const int32_t first = (int32_t)sc.nodes.size();
-    set_links(sc.nodes[id], first, -1);
+    if (depth + 1 >= RT_OCT_STACK) { out.too_deep = true; set_links(self, (int32_t)out.refs.size(), 0); return; }
+    const int32_t first = (int32_t)out.nodes.size();
+    set_links(self, first, -1);
     float ini[3], end[3];
-    for (int k = 0; k < 3; k++) { ini[k] = sc.nodes[id].a[k]; end[k] = sc.nodes[id].b[k]; }
-    sc.nodes.resize(sc.nodes.size() + 8);
+    for (int k = 0; k < 3; k++) { ini[k] = self.a[k]; end[k] = self.b[k]; }   // before out.nodes grows: self may live in it
+    out.nodes.resize(out.nodes.size() + 8);
+    RtNode kids[8];
     for (int c = 0; c < 8; c++) {
       float ci[3], ce[3]; child_box(ini, end, c, ci, ce);
-      set_bounds(sc.nodes[first + c], ci, ce);
+      kids[c] = RtNode{}; set_bounds(kids[c], ci, ce);
     }
-    std::vector<int32_t> sub;
-    for (int c = 0; c < 8; c++) {
+    auto members = [&](int c, std::vector<int32_t>& sub) {
       float ci[3], ce[3];
-      for (int k = 0; k < 3; k++) { ci[k] = sc.nodes[first + c].a[k]; ce[k] = sc.nodes[first + c].b[k]; }
+      for (int k = 0; k < 3; k++) { ci[k] = kids[c].a[k]; ce[k] = kids[c].b[k]; }
       sub.clear();
-      for (int32_t t : tris) if (triangle_touches_box(&sc.tri_verts[9 * (size_t)t], ci, ce)) sub.push_back(t);
-      fill(first + c, sub, depth + 1, false);
+      for (int32_t t : tris) if (tri_axes_touch_box(axes[t], ci, ce)) sub.push_back(t);
+    };
+    // large sets: the eight children are filtered and built concurrently while threads are to be had
+    const bool fork = tris.size() >= 4096;
+    Sub part[8];
+    std::thread th[8];
+    bool forked[8] = {false, false, false, false, false, false, false, false};
+    for (int c = 0; c < 8; c++) {
+      auto job = [this, c, depth, &kids, &part, &members]() {
+        std::vector<int32_t> sub; members(c, sub);
+        fill(kids[c], sub, depth + 1, false, part[c]);
+      };
+      if (fork && c < 7 && spare_threads.fetch_sub(1) > 0) { th[c] = std::thread(job); forked[c] = true; }
+      else { if (fork && c < 7) spare_threads.fetch_add(1); job(); }
+    }
+    for (int c = 0; c < 8; c++) if (forked[c]) { th[c].join(); spare_threads.fetch_add(1); }
+    // splice: child c's descendants follow those of children 0..c-1
+    for (int c = 0; c < 8; c++) {
+      const int32_t node_base = (int32_t)out.nodes.size(), ref_base = (int32_t)out.refs.size();
+      int32_t f, n; get_links(kids[c], f, n);
+      set_links(kids[c], f + (n < 0 ? node_base : ref_base), n);
+      out.nodes[first + c] = kids[c];
+      for (RtNode d : part[c].nodes) {
+        get_links(d, f, n);
+        set_links(d, f + (n < 0 ? node_base : ref_base), n);
+        out.nodes.push_back(d);
+      }
+      out.refs.insert(out.refs.end(), part[c].refs.begin(), part[c].refs.end());
+      if (part[c].max_depth > out.max_depth) out.max_depth = part[c].max_depth;
+      out.too_deep |= part[c].too_deep;
     }
   }
 
   void build() {   // main.cu:25-31
     const float ini[3] = {-RT_INF / 4, -RT_INF / 4, RT_INF / 4}, end[3] = {RT_INF / 4, RT_INF / 4, -RT_INF / 4};
-    sc.nodes.clear(); sc.leaf_refs.clear();
-    sc.nodes.resize(1);
-    set_bounds(sc.nodes[0], ini, end);
-    std::vector<int32_t> all;
     const int32_t nt = (int32_t)(sc.tri_verts.size() / 9);
-    for (int32_t t = 0; t < nt; t++) if (triangle_touches_box(&sc.tri_verts[9 * (size_t)t], ini, end)) all.push_back(t);
-    fill(0, all, 0, true);
+    axes.resize(nt);
+    for (int32_t t = 0; t < nt; t++) axes[t] = make_tri_axes(&sc.tri_verts[9 * (size_t)t]);
+    std::vector<int32_t> all;
+    for (int32_t t = 0; t < nt; t++) if (tri_axes_touch_box(axes[t], ini, end)) all.push_back(t);
+    unsigned hw = std::thread::hardware_concurrency();
+    if (const char* e = getenv("RT_AMD_BUILD_THREADS")) hw = (unsigned)std::max(1, atoi(e));
+    spare_threads = (int)std::min(std::max(hw, 1u), 32u) - 1;
+    RtNode root{}; set_bounds(root, ini, end);
+    Sub rest;
+    fill(root, all, 0, true, rest);
+    if (rest.too_deep)
+      throw Fail{RT_ERR_LIMIT, "octree would be deeper than the 20-entry traversal stack (more than 50 triangles meet in one point)"};
+    // the root takes index 0 and its descendants follow: shift every link by one node
+    sc.nodes.clear(); sc.nodes.reserve(rest.nodes.size() + 2);
+    int32_t f, n; get_links(root, f, n); set_links(root, f + 1, n);
+    sc.nodes.push_back(root);
+    for (RtNode d : rest.nodes) { get_links(d, f, n); if (n < 0) set_links(d, f + 1, n); sc.nodes.push_back(d); }
+    sc.leaf_refs.swap(rest.refs);
   }
 };
 

@@ -100,3 +100,14 @@ def test_png_writer_roundtrip(tmp_path):
         rt.write_png(p, img)
         back = np.array(Image.open(p).convert("RGB"))
         assert np.array_equal(back, img)
+
+
+def test_tree_does_not_depend_on_the_number_of_build_threads(monkeypatch):
+    trees = []
+    for threads in ("1", "3", "8"):
+        monkeypatch.setenv("RT_AMD_BUILD_THREADS", threads)
+        s = rt.Scene("scenes/meshDragon.json", 64, 64, 3)
+        k, b, r = s.tree()
+        trees.append((k.copy(), b.copy(), r.copy()))
+    for k, b, r in trees[1:]:
+        assert np.array_equal(k, trees[0][0]) and np.array_equal(_bits(b), _bits(trees[0][1])) and np.array_equal(r, trees[0][2])
