@@ -23,7 +23,7 @@ $(CSRC)/%.o: $(CSRC)/%.hip $(CSRC)/rt_kernels.h $(CSRC)/rt_internal.h $(CSRC)/rt
 	$(HIPCC) $(HIPFLAGS) -c $< -o $@
 
 $(LIB): $(CSRC)/rt_host.o $(HIPOBJS)
-	$(HIPCC) --offload-arch=$(ARCH) -shared -fPIC -pthread -o $@ $^
+	$(HIPCC) --offload-arch=$(ARCH) -shared -fPIC -pthread -o $@ $^ -lz
 
 $(RUN): $(CSRC)/run_main.cpp $(LIB) include/rt_amd.h
 	$(CXX) $(HOSTFLAGS) $< -o $@ -Lraytracer_amd -lrt_amd -Wl,-rpath,'$$ORIGIN'

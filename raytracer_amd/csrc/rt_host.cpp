@@ -18,6 +18,8 @@
 #include <thread>
 #include <vector>
 
+#include <zlib.h>
+
 #include "rt_internal.h"
 
 // ------------------------------------------------------------------ errors
@@ -837,28 +839,52 @@ extern "C" int rt_scene_dump_camera(const rt_scene* s, float* o) {
   return RT_OK;
 }
 
-// 8-bit RGB, filter 0 on every row, zlib stream of stored deflate blocks (no compression library needed).
+// 8-bit RGB, filter 0 on every row (display.cpp:7-16 writes the same pixels through lodepng).  The scanlines are cut
+// into bands that are deflated concurrently as raw streams ending on a byte boundary (Z_SYNC_FLUSH; the last one
+// Z_FINISH) and concatenated behind one zlib header; the Adler-32 of the whole is combined from the bands'.
 extern "C" int rt_write_png(const char* path, int width, int height, const uint8_t* rgb) {
   if (!path || !rgb || width < 1 || height < 1) { rt_set_error("rt_write_png: bad argument"); return RT_ERR_ARG; }
-  const size_t row = (size_t)width * 3, raw_n = (row + 1) * (size_t)height;
-  std::vector<uint8_t> z; z.reserve(raw_n + raw_n / 65535 * 5 + 16);
+  const size_t row = (size_t)width * 3;
+  const int band_rows = std::max(1, (int)((1u << 20) / (row + 1)));          // about 1 MiB of scanlines per band
+  const int n_bands = (height + band_rows - 1) / band_rows;
+  struct Band { std::vector<uint8_t> z; uLong adler = 1; size_t raw_n = 0; int rc = Z_OK; };
+  std::vector<Band> bands(n_bands);
+  auto pack = [&](int bi) {
+    Band& B = bands[bi];
+    const int y0 = bi * band_rows, y1 = std::min(height, y0 + band_rows);
+    std::vector<uint8_t> raw((row + 1) * (size_t)(y1 - y0));
+    for (int y = y0; y < y1; y++) { raw[(row + 1) * (y - y0)] = 0; memcpy(&raw[(row + 1) * (y - y0) + 1], rgb + row * y, row); }
+    B.raw_n = raw.size();
+    B.adler = adler32(1, raw.data(), (uInt)raw.size());
+    z_stream zs; memset(&zs, 0, sizeof zs);
+    if ((B.rc = deflateInit2(&zs, 1, Z_DEFLATED, -15, 8, Z_DEFAULT_STRATEGY)) != Z_OK) return;
+    B.z.resize(deflateBound(&zs, (uLong)raw.size()) + 16);
+    zs.next_in = raw.data(); zs.avail_in = (uInt)raw.size(); zs.next_out = B.z.data(); zs.avail_out = (uInt)B.z.size();
+    const int last = bi == n_bands - 1;
+    const int r = deflate(&zs, last ? Z_FINISH : Z_SYNC_FLUSH);
+    B.rc = (last ? r == Z_STREAM_END : (r == Z_OK && zs.avail_in == 0)) ? Z_OK : Z_BUF_ERROR;
+    B.z.resize(zs.total_out);
+    deflateEnd(&zs);
+  };
+  {
+    unsigned nt = std::min<unsigned>(std::max(1u, std::thread::hardware_concurrency()), 16u);
+    nt = std::min<unsigned>(nt, (unsigned)n_bands);
+    std::atomic<int> next{0};
+    auto worker = [&]() { for (int bi; (bi = next.fetch_add(1)) < n_bands;) pack(bi); };
+    std::vector<std::thread> th;
+    for (unsigned t = 1; t < nt; t++) th.emplace_back(worker);
+    worker();
+    for (auto& t : th) t.join();
+  }
+  std::vector<uint8_t> z;
   z.push_back(0x78); z.push_back(0x01);
-  uint32_t a = 1, b = 0;   // Adler-32 over the filtered scanlines
-  std::vector<uint8_t> raw(raw_n);
-  for (int y = 0; y < height; y++) { raw[(row + 1) * y] = 0; memcpy(&raw[(row + 1) * y + 1], rgb + row * y, row); }
-  for (size_t i = 0; i < raw_n;) {
-    const size_t n = std::min<size_t>(5552, raw_n - i);
-    for (size_t k = 0; k < n; k++) { a += raw[i + k]; b += a; }
-    a %= 65521; b %= 65521; i += n;
+  uLong adler = 1;
+  for (int bi = 0; bi < n_bands; bi++) {
+    if (bands[bi].rc != Z_OK) { rt_set_error("rt_write_png: deflate failed"); return RT_ERR_NOMEM; }
+    z.insert(z.end(), bands[bi].z.begin(), bands[bi].z.end());
+    adler = bi == 0 ? bands[bi].adler : adler32_combine(adler, bands[bi].adler, (z_off_t)bands[bi].raw_n);
   }
-  for (size_t i = 0; i < raw_n;) {
-    const size_t n = std::min<size_t>(65535, raw_n - i);
-    z.push_back(i + n == raw_n ? 1 : 0);
-    z.push_back(n & 0xFF); z.push_back(n >> 8); z.push_back(~n & 0xFF); z.push_back((~n >> 8) & 0xFF);
-    z.insert(z.end(), raw.begin() + i, raw.begin() + i + n);
-    i += n;
-  }
-  put_be32(z, (b << 16) | a);
+  put_be32(z, (uint32_t)adler);
   std::vector<uint8_t> out = {0x89, 'P', 'N', 'G', 0x0D, 0x0A, 0x1A, 0x0A};
   std::vector<uint8_t> ihdr; put_be32(ihdr, (uint32_t)width); put_be32(ihdr, (uint32_t)height);
   ihdr.push_back(8); ihdr.push_back(2); ihdr.push_back(0); ihdr.push_back(0); ihdr.push_back(0);
