@@ -89,6 +89,11 @@ def cpu_baseline(args, threads):
 
 def main():
     args = parse_args()
+    # Rank 0 prints exactly one line on stdout.  Libraries (RCCL's version banner among them) write to file descriptor 1
+    # behind Python's back, so descriptor 1 points at stderr until the result line is due.
+    sys.stdout.flush()
+    real_stdout = os.dup(1)
+    os.dup2(2, 1)
     import torch
     import torch.distributed as dist
     import raytracer_amd as rt
@@ -104,8 +109,6 @@ def main():
         raise SystemExit("bench.py needs a GPU: the render path has no CPU fallback")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    if world > 1:
-        dist.init_process_group("nccl", device_id=dev)
 
     W, H = args.width, args.height
     base_dir = None
@@ -119,44 +122,67 @@ def main():
     info = scene.info()
     ds = rt.DeviceScene(scene, device=local_rank)
     nb_max = ds.band_count(BAND_ROWS, 0, world)            # rank 0 owns the most bands
-    local = torch.zeros((nb_max * BAND_ROWS, W, 3), dtype=torch.uint8, device=dev)
-    gathered = [torch.zeros_like(local) for _ in range(world)] if (world > 1 and rank == 0) else None
+    dist_on = world > 1 or os.environ.get("RT_BENCH_FORCE_DIST") == "1"   # the latter: rehearse the exchange on one GPU
+    if dist_on and not dist.is_initialized():
+        dist.init_process_group("nccl", device_id=dev)
+    # Two frame tiles per rank: the gather of frame k runs on the collective's stream while frame k+1 is rendered.
+    local = [torch.zeros((nb_max * BAND_ROWS, W, 3), dtype=torch.uint8, device=dev) for _ in range(2 if dist_on else 1)]
+    gathered = [[torch.zeros_like(local[0]) for _ in range(world)] for _ in local] if (dist_on and rank == 0) else None
+    pending = [None, None]
     stream = torch.cuda.current_stream()
 
-    def step(flags=0, want_stats=False):
-        st = ds.render_bands_into(local.data_ptr(), BAND_ROWS, rank, world, stream=stream.cuda_stream, flags=flags,
+    def step(k, flags=0, want_stats=False):
+        b = k % len(local)
+        if pending[b] is not None:
+            pending[b].wait()          # the render stream waits for the gather that last read this tile
+            pending[b] = None
+        st = ds.render_bands_into(local[b].data_ptr(), BAND_ROWS, rank, world, stream=stream.cuda_stream, flags=flags,
                                   want_stats=want_stats)
-        if world > 1:
-            dist.gather(local, gathered, dst=0)
+        if dist_on:
+            pending[b] = dist.gather(local[b], gathered[b] if rank == 0 else None, dst=0, async_op=True)
         return st
 
+    def drain():
+        for b in range(len(pending)):
+            if pending[b] is not None:
+                pending[b].wait()
+                pending[b] = None
+
     # ray counts of this rank's share (deterministic; read back once, outside the timed region)
-    st = step(want_stats=True)
+    st = step(0, want_stats=True)
+    drain()
     rays_t = torch.tensor([st["rays"], st["shadow_rays"]], dtype=torch.int64, device=dev)
-    if world > 1:
+    if dist_on:
         dist.all_reduce(rays_t)
     rays_total, shadow_total = int(rays_t[0]), int(rays_t[1])
 
-    for _ in range(args.warmup):
-        step()
+    for k in range(args.warmup):
+        step(k)
+    drain()
+    # The kernel's own duration: HIP events around the launch, on the stream it is launched on.
     ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
-    if world > 1:
+    if dist_on:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for k in range(args.steps):
+        b = k % len(local)
+        if pending[b] is not None:
+            pending[b].wait()
+            pending[b] = None
         ev[k][0].record(stream)
-        ds.render_bands_into(local.data_ptr(), BAND_ROWS, rank, world, stream=stream.cuda_stream)
+        ds.render_bands_into(local[b].data_ptr(), BAND_ROWS, rank, world, stream=stream.cuda_stream)
         ev[k][1].record(stream)
-        if world > 1:
-            dist.gather(local, gathered, dst=0)
+        if dist_on:
+            pending[b] = dist.gather(local[b], gathered[b] if rank == 0 else None, dst=0, async_op=True)
+    drain()
     torch.cuda.synchronize()
-    if world > 1:
+    if dist_on:
         dist.barrier()
     elapsed = time.perf_counter() - t0
     kernel_ms = sum(a.elapsed_time(b) for a, b in ev) / max(args.steps, 1)
     tt = torch.tensor([elapsed, kernel_ms], dtype=torch.float64, device=dev)
-    if world > 1:
+    if dist_on:
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
     elapsed, kernel_ms = float(tt[0]), float(tt[1])
 
@@ -177,7 +203,7 @@ def main():
         if ref is None and world == 1:
             # no recorded reference counts for this workload: take them from the instrumented kernel variant, whose
             # counts the parity tests hold identical to the oracle's (one extra launch, outside the timed region)
-            sc = ds.render_bands_into(local.data_ptr(), BAND_ROWS, rank, world, stream=stream.cuda_stream,
+            sc = ds.render_bands_into(local[0].data_ptr(), BAND_ROWS, rank, world, stream=stream.cuda_stream,
                                       flags=rt.RT_RENDER_COUNT_TESTS, want_stats=True)
             ref = {"rays": sc["rays"], "node_tests": sc["node_tests"], "tri_tests": sc["tri_tests"], "sphere_tests": sc["sphere_tests"]}
             counts_from = "instrumented kernel variant"
@@ -200,15 +226,18 @@ def main():
                      "the reference's own scene and mesh files (deterministic, no RNG anywhere in the path)"),
             "config": {"workload": "%s %dx%d depth %d" % (os.path.join("scenes", os.path.basename(args.scene)), W, H, args.depth), "rays_per_frame": rays_total,
                        "shadow_rays_per_frame": shadow_total, "triangles": info["n_triangles"], "octree_nodes": info["n_nodes"],
-                       "partition": "%d-row bands round-robin over %d GPU(s), one RCCL gather" % (BAND_ROWS, world),
+                       "partition": "%d-row bands round-robin over %d GPU(s), one RCCL gather per frame overlapped with the next frame's render" % (BAND_ROWS, world),
                        "library": rt.version()},
             "roofline": roofline,
         }
         if world == 1 and not args.no_cpu_baseline:
             threads = min(int(os.environ.get("OMP_NUM_THREADS", "0")) or (os.cpu_count() or 1), 16)
             out["cpu_baseline"] = cpu_baseline(args, threads)
+        sys.stdout.flush()
+        os.dup2(real_stdout, 1)
         print(json.dumps(out), flush=True)
-    if world > 1:
+        os.dup2(2, 1)
+    if dist_on:
         dist.destroy_process_group()
 
 
