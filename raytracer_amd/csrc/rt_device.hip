@@ -68,7 +68,7 @@ extern "C" int rt_scene_upload(const rt_scene* s, int device, rt_dscene** out) {
   UP(spheres, s->spheres) UP(lights, s->lights) UP(materials, s->materials) UP(mat_index, s->mat_index)
   UP(mesh_mat_first, s->mesh_mat_first) UP(mesh_mat_count, s->mesh_mat_count)
 #undef UP
-  V.n_spheres = (int32_t)s->spheres.size(); V.n_lights = (int32_t)s->lights.size(); V.has_oct = s->nodes.empty() ? 0 : 1;
+  V.n_spheres = (int32_t)s->spheres.size(); V.n_lights = (int32_t)s->lights.size(); V.has_oct = s->nodes.empty() ? 0 : 1; V.n_wnodes = (int32_t)s->nodes.size();
   void* c = nullptr;
   if (hipMalloc(&c, RT_COUNTER_COPIES * RT_COUNTER_STRIDE * sizeof(unsigned long long)) != hipSuccess) { rt_dscene_destroy(d); rt_set_error("hipMalloc(counters) failed"); return RT_ERR_DEVICE; }
   d->allocs.push_back(c); d->d_counters = (unsigned long long*)c;

@@ -724,21 +724,26 @@ void load_scene_into(rt_scene& sc, const std::string& scene_path, const std::str
       t.id = sc.leaf_refs[r];
     }
     sc.nodes.push_back(RtNode{});   // pad; not counted in info.n_nodes
-    sc.wnodes.assign(sc.nodes.size(), RtWaveNode{});
+    sc.wnodes.assign(sc.nodes.size() * RT_NODE_VARIANTS, RtWaveNode{});
     for (size_t i = 0; i + 1 < sc.nodes.size(); i++) {
       const RtNode& n = sc.nodes[i];
-      RtWaveNode& w = sc.wnodes[i];
-      w.lohi[0] = n.a[0]; w.lohi[1] = n.b[0]; w.lohi[2] = n.a[1]; w.lohi[3] = n.b[1]; w.lohi[4] = n.b[2]; w.lohi[5] = n.a[2];
+      const float lo[3] = {n.a[0], n.a[1], n.b[2]}, hi[3] = {n.b[0], n.b[1], n.a[2]};
       int32_t first, count;
       memcpy(&first, &n.a[3], 4); memcpy(&count, &n.b[3], 4);
-      w.first = first;
-      if (count >= 0) { w.meta = (uint32_t)count; continue; }
-      uint32_t occupied = 0;
-      for (int c = 0; c < 8; c++) {
-        int32_t cc; memcpy(&cc, &sc.nodes[first + c].b[3], 4);
-        if (cc != 0) occupied |= 1u << c;
+      uint32_t meta = (uint32_t)count;
+      if (count < 0) {
+        uint32_t occupied = 0;
+        for (int c = 0; c < 8; c++) {
+          int32_t cc; memcpy(&cc, &sc.nodes[first + c].b[3], 4);
+          if (cc != 0) occupied |= 1u << c;
+        }
+        meta = 0x80000000u | occupied;
       }
-      w.meta = 0x80000000u | occupied;
+      for (int v = 0; v < RT_NODE_VARIANTS; v++) {
+        RtWaveNode& w = sc.wnodes[(size_t)v * sc.nodes.size() + i];
+        for (int k = 0; k < 3; k++) { const bool sw = (v >> k) & 1; w.lohi[2 * k] = sw ? hi[k] : lo[k]; w.lohi[2 * k + 1] = sw ? lo[k] : hi[k]; }
+        w.first = first; w.meta = meta;
+      }
     }
   }
   I.build_seconds = seconds_since(t_build);

@@ -53,8 +53,15 @@ struct RtNode { float a[4]; float b[4]; };
 
 // The same node as the wave-synchronous kernel reads it, 32 B = one 8-dword scalar load.  The two planes of an
 // axis sit in adjacent dwords so that a packed-fp32 instruction can take them straight from an SGPR pair.
-//   lo.x hi.x lo.y hi.y | lo.z hi.z first meta     (lo / hi = min / max corner: ini = lo.x lo.y hi.z, end = hi.x hi.y lo.z)
+//   p.x q.x p.y q.y | p.z q.z first meta
 //   meta: leaf -> number of triangles (0..50); branch -> 0x80000000 | bit c set when child c is not an empty leaf
+// The array is stored RT_NODE_VARIANTS = 8 times over (variant v of node i is record v * n + i, n counting the pad
+// record, so that a walk stays inside one dense copy):  in variant v the pair of axis k is
+// (lo, hi) when bit k of v is clear and (hi, lo) when it is set, lo / hi being the min / max corner
+// (ini = lo.x lo.y hi.z, end = hi.x hi.y lo.z).  A wave whose rays all have the same direction signs walks the
+// variant in which every pair is already (near plane, far plane) and saves the six min / max per node test; a trace
+// only ever touches one variant, so the cache footprint of a trace is that of a single copy.
+#define RT_NODE_VARIANTS 8
 struct RtWaveNode { float lohi[6]; int32_t first; uint32_t meta; };
 
 // Triangle intersection record, 48 B = three 16-byte loads:
@@ -76,7 +83,7 @@ struct rt_scene {
   std::vector<int32_t> mat_index;                 // concatenated material lists (spheres, then meshes)
   std::vector<int32_t> mesh_mat_first, mesh_mat_count;
   std::vector<RtNode> nodes;                      // nodes[0] = root (always a branch) when non-empty
-  std::vector<RtWaveNode> wnodes;                 // nodes in the wave kernel's layout (same indices, same pad record)
+  std::vector<RtWaveNode> wnodes;                 // nodes in the wave kernel's layout: RT_NODE_VARIANTS copies of nodes.size() records
   std::vector<int32_t> leaf_refs;
   std::vector<RtTriGeom> tri_geom;
   std::vector<RtTriLeaf> tri_leaf;                // intersection records repeated in leaf order (index space of leaf_refs), plus one pad record

@@ -38,7 +38,7 @@ __device__ __forceinline__ uint64_t uni64(uint64_t v) {
 //   stop_t : >= 0 for a shadow ray: the lane drops out as soon as its t falls below stop_t, because
 //            only "t < light distance" is consumed (ray.cu:70) and t never grows; < 0 = never
 template <bool COUNT>
-__device__ __forceinline__ void trace_wave(const float4* __restrict__ nodes, const float4* __restrict__ tri_leaf,
+__device__ __forceinline__ void trace_wave(const float4* __restrict__ nodes, int n_wnodes, const float4* __restrict__ tri_leaf,
                                            const RtSphere* __restrict__ spheres, int n_spheres, bool has_oct, bool want,
                                            const RtVec3& e, const RtVec3& d, float stop_t, Hit& hit, WaveStack& st,
                                            int lane, Tally& tl) {
@@ -51,11 +51,30 @@ __device__ __forceinline__ void trace_wave(const float4* __restrict__ nodes, con
   const RtVec3 inv = {1.f / d.x, 1.f / d.y, 1.f / d.z};   // only feeds the conservative classification
   const unsigned zmask = (d.x == 0.f ? 1u : 0u) | (d.y == 0.f ? 2u : 0u) | (d.z == 0.f ? 4u : 0u);
   const bool any_zero = (__builtin_amdgcn_ballot_w64(zmask != 0u) & live) != 0ull;
+  // Zero components usually come from an axis-parallel directional light, the same for every ray of the wave: then the
+  // pattern is wave-uniform and the node test specialised on it runs (0 = not uniform, or no zero at all).
+  uint32_t zpat = 0u;
+  if (any_zero) {
+    const uint64_t zx = __builtin_amdgcn_ballot_w64(d.x == 0.f) & live, zy = __builtin_amdgcn_ballot_w64(d.y == 0.f) & live,
+                   zz = __builtin_amdgcn_ballot_w64(d.z == 0.f) & live;
+    if ((zx == 0ull || zx == live) && (zy == 0ull || zy == live) && (zz == 0ull || zz == live))
+      zpat = (zx ? 1u : 0u) | (zy ? 2u : 0u) | (zz ? 4u : 0u);
+    if (zpat == 7u) zpat = 0u;   // cannot happen for a direction; the general form copes with anything
+  }
+  zpat = uni(zpat);
+  // Direction signs: when every ray of the wave agrees on all three (and none is zero), the wave reads the node
+  // variant whose plane pairs are already in (near, far) order for those signs.  Otherwise variant 0 = (lo, hi).
+  const uint64_t sx = __builtin_amdgcn_ballot_w64(d.x < 0.f) & live, sy = __builtin_amdgcn_ballot_w64(d.y < 0.f) & live,
+                 sz = __builtin_amdgcn_ballot_w64(d.z < 0.f) & live;
+  const bool presorted = !any_zero && (sx == 0ull || sx == live) && (sy == 0ull || sy == live) && (sz == 0ull || sz == live);
+  const uint32_t variant = uni(presorted ? ((sx ? 1u : 0u) | (sy ? 2u : 0u) | (sz ? 4u : 0u)) : 0u);   // uni(): keeps the node addresses scalar
+  nodes += 2 * (size_t)variant * (size_t)n_wnodes;   // each variant is a dense copy of the whole array
 
   if (has_oct) {
     // The walk goes over the children of one branch at a time: `rem` holds the children still to be tested (bit c =
     // child c, lowest first = the reference's order 0..7).  Empty leaves are left out of `rem` from the start: testing
     // one has no effect on any result, only on the node-test count, so the instrumented variant keeps them.
+    constexpr uint32_t NS = 2;   // float4 per node record
     uint32_t top_first = uni(__float_as_uint(nodes[1].z));   // the root is entered without a test (ray.cu:36-38)
     uint32_t rem = COUNT ? 0xffu : (uni(__float_as_uint(nodes[1].w)) & 0xffu);
     uint64_t top_mask = live;
@@ -64,7 +83,7 @@ __device__ __forceinline__ void trace_wave(const float4* __restrict__ nodes, con
     // always requested as soon as it is known (next sibling: before the current child is classified; first child of
     // a branch: on descent or ascent), so its latency hides behind the classification.
     float4 nx_a = {0, 0, 0, 0}, nx_b = {0, 0, 0, 0};
-    { const uint32_t i = top_first + (uint32_t)__builtin_ctz(rem | 0x100u); nx_a = nodes[2 * i]; nx_b = nodes[2 * i + 1]; }
+    { const uint32_t i = top_first + (uint32_t)__builtin_ctz(rem | 0x100u); nx_a = nodes[NS * i]; nx_b = nodes[NS * i + 1]; }
     for (;;) {
       const uint64_t mine_m = top_mask & live;
       if (rem == 0u || mine_m == 0ull) {   // branch exhausted, or every lane that entered it is decided
@@ -73,26 +92,43 @@ __device__ __forceinline__ void trace_wave(const float4* __restrict__ nodes, con
         top_first = __builtin_amdgcn_readlane(st.first, sp); rem = __builtin_amdgcn_readlane(st.cur, sp);
         top_mask = ((uint64_t)(uint32_t)__builtin_amdgcn_readlane(st.mask_hi, sp) << 32) | (uint32_t)__builtin_amdgcn_readlane(st.mask_lo, sp);
         const uint32_t i = top_first + (uint32_t)__builtin_ctz(rem);   // entries are only pushed with children left
-        nx_a = nodes[2 * i]; nx_b = nodes[2 * i + 1];
+        nx_a = nodes[NS * i]; nx_b = nodes[NS * i + 1];
         continue;
       }
       rem &= rem - 1u;
       const float4 na = nx_a, nb = nx_b;
-      if (rem != 0u) { const uint32_t i = top_first + (uint32_t)__builtin_ctz(rem); nx_a = nodes[2 * i]; nx_b = nodes[2 * i + 1]; }
+      if (rem != 0u) { const uint32_t i = top_first + (uint32_t)__builtin_ctz(rem); nx_a = nodes[NS * i]; nx_b = nodes[NS * i + 1]; }
       if (COUNT) { if (uni(__float_as_uint(nb.w)) != 0u) tl.w[1]++; if ((mine_m >> lane) & 1ull) tl.node++; }   // w[1]: iterations the plain variant also makes
       // conservative slab classification first; the exact test only where some lane is within rounding of a boundary
       uint64_t acc_m, und_m;
-      if (!any_zero) {
+      if (presorted) {
         bool c_acc, c_rej;
-        rt_node_slab_fast(na.x, na.y, na.z, na.w, nb.x, nb.y, e, inv, hit.t, c_acc, c_rej);
+        rt_node_slab_presorted(na.x, na.y, na.z, na.w, nb.x, nb.y, e, inv, hit.t, c_acc, c_rej);
 #ifdef RT_ABL_NODE2
         {   // ablation: evaluate the classification a second time on values the compiler cannot fold
           float t2 = hit.t; asm volatile("" : "+v"(t2));
           bool a2, r2;
-          rt_node_slab_fast(na.x, na.y, na.z, na.w, nb.x, nb.y, e, inv, t2, a2, r2);
+          rt_node_slab_presorted(na.x, na.y, na.z, na.w, nb.x, nb.y, e, inv, t2, a2, r2);
           asm volatile("" :: "s"(__builtin_amdgcn_ballot_w64(a2)), "s"(__builtin_amdgcn_ballot_w64(r2)));
         }
 #endif
+        acc_m = __builtin_amdgcn_ballot_w64(c_acc) & mine_m;
+        und_m = mine_m & ~(acc_m | __builtin_amdgcn_ballot_w64(c_rej));
+      } else if (!any_zero) {
+        bool c_acc, c_rej;
+        rt_node_slab_fast(na.x, na.y, na.z, na.w, nb.x, nb.y, e, inv, hit.t, c_acc, c_rej);
+        acc_m = __builtin_amdgcn_ballot_w64(c_acc) & mine_m;
+        und_m = mine_m & ~(acc_m | __builtin_amdgcn_ballot_w64(c_rej));
+      } else if (zpat != 0u) {
+        bool c_acc = false, c_rej = false;
+        switch (zpat) {
+          case 1u: rt_node_slab_zero<true, false, false>(na.x, na.y, na.z, na.w, nb.x, nb.y, e, inv, hit.t, c_acc, c_rej); break;
+          case 2u: rt_node_slab_zero<false, true, false>(na.x, na.y, na.z, na.w, nb.x, nb.y, e, inv, hit.t, c_acc, c_rej); break;
+          case 3u: rt_node_slab_zero<true, true, false>(na.x, na.y, na.z, na.w, nb.x, nb.y, e, inv, hit.t, c_acc, c_rej); break;
+          case 4u: rt_node_slab_zero<false, false, true>(na.x, na.y, na.z, na.w, nb.x, nb.y, e, inv, hit.t, c_acc, c_rej); break;
+          case 5u: rt_node_slab_zero<true, false, true>(na.x, na.y, na.z, na.w, nb.x, nb.y, e, inv, hit.t, c_acc, c_rej); break;
+          default: rt_node_slab_zero<false, true, true>(na.x, na.y, na.z, na.w, nb.x, nb.y, e, inv, hit.t, c_acc, c_rej); break;
+        }
         acc_m = __builtin_amdgcn_ballot_w64(c_acc) & mine_m;
         und_m = mine_m & ~(acc_m | __builtin_amdgcn_ballot_w64(c_rej));
       } else {
@@ -108,7 +144,9 @@ __device__ __forceinline__ void trace_wave(const float4* __restrict__ nodes, con
         RtVec3 dd = d, ee = e; float T = hit.t;
         asm volatile("" : "+v"(dd.x), "+v"(dd.y), "+v"(dd.z), "+v"(ee.x), "+v"(ee.y), "+v"(ee.z), "+v"(T));
         const RtRayConst rc = rt_ray_const(dd);
-        const RtVec3 ini = {na.x, na.z, nb.y}, end = {na.y, na.w, nb.x};
+        // corners in the reference's convention (ini = lo.x lo.y hi.z, end = hi.x hi.y lo.z) out of the variant's pairs
+        const bool wx = (variant & 1u) != 0u, wy = (variant & 2u) != 0u, wz = (variant & 4u) != 0u;
+        const RtVec3 ini = {wx ? na.y : na.x, wy ? na.w : na.z, wz ? nb.x : nb.y}, end = {wx ? na.x : na.y, wy ? na.z : na.w, wz ? nb.y : nb.x};
         const float S = rt_node_score(ini, end, ee, dd, rc, rt_t_float(rc, T));
         uint64_t pos_m = __builtin_amdgcn_ballot_w64(S > 0.f);
         const uint64_t tie_m = __builtin_amdgcn_ballot_w64(S == 0.f) & und_m;
@@ -133,7 +171,7 @@ __device__ __forceinline__ void trace_wave(const float4* __restrict__ nodes, con
         }
         top_first = first; rem = crem; top_mask = acc_m;
         const uint32_t i = top_first + (uint32_t)__builtin_ctz(rem);
-        nx_a = nodes[2 * i]; nx_b = nodes[2 * i + 1];
+        nx_a = nodes[NS * i]; nx_b = nodes[NS * i + 1];
         continue;
       }
       const int32_t count = (int32_t)meta;
@@ -281,7 +319,7 @@ __global__ __launch_bounds__(RT_BLOCK, BOUNCE ? RT_WAVES_PER_SIMD_BOUNCE : RT_WA
     const RtCamera cam, const RowMap rows, const float4* __restrict__ nodes, const float4* __restrict__ tri_leaf,
     const float4* __restrict__ tri_geom, const float4* __restrict__ tri_shade, const RtSphere* __restrict__ spheres,
     const RtLight* __restrict__ lights, const RtMaterial* __restrict__ materials, const int32_t* __restrict__ mat_index,
-    const int32_t* __restrict__ mesh_mat_first, const int32_t* __restrict__ mesh_mat_count, int n_spheres, int n_lights, int has_oct,
+    const int32_t* __restrict__ mesh_mat_first, const int32_t* __restrict__ mesh_mat_count, int n_spheres, int n_lights, int has_oct, int n_wnodes,
     uint8_t* __restrict__ rgb, int32_t* __restrict__ ids, float* __restrict__ ts, unsigned long long* __restrict__ counters_all, int tally) {
   unsigned long long* const counters = counters_all + ((blockIdx.x + blockIdx.y) & (RT_COUNTER_COPIES - 1)) * RT_COUNTER_STRIDE;
   __shared__ float parked[ShadeState<BOUNCE>::WORDS * RT_BLOCK];
@@ -350,7 +388,7 @@ __global__ __launch_bounds__(RT_BLOCK, BOUNCE ? RT_WAVES_PER_SIMD_BOUNCE : RT_WA
       if (want) tl.traced++;
       park<BOUNCE>(sh, my_park);
       asm volatile("" ::: "memory");
-      trace_wave<COUNT>(nodes, tri_leaf, spheres, n_spheres, has_oct != 0, want, tr_e, tr_d, stop_t, h, st, lane, tl);
+      trace_wave<COUNT>(nodes, n_wnodes, tri_leaf, spheres, n_spheres, has_oct != 0, want, tr_e, tr_d, stop_t, h, st, lane, tl);
       asm volatile("" ::: "memory");
       unpark<BOUNCE>(sh, my_park);
     }
@@ -560,7 +598,7 @@ void rt_launch_wave_kernel(const RtDeviceView& V, const RowMap& rows, bool bounc
 #define LAUNCH(B, C)                                                                                                             \
   hipLaunchKernelGGL((render_wave<B, C>), grid, block, 0, stream, V.cam, rows, V.wnodes, V.tri_leaf, V.tri_geom, V.tri_shade,     \
                      V.spheres, V.lights, V.materials, V.mat_index, V.mesh_mat_first, V.mesh_mat_count, V.n_spheres, V.n_lights, \
-                     V.has_oct, rgb, ids, ts, counters, tally ? 1 : 0)
+                     V.has_oct, V.n_wnodes, rgb, ids, ts, counters, tally ? 1 : 0)
   if (bounce && count) LAUNCH(true, true);
   else if (bounce) LAUNCH(true, false);
   else if (count) LAUNCH(false, true);

@@ -361,12 +361,7 @@ RT_HD int rt_node_slab_class(const RtVec3& lo, const RtVec3& hi, const RtVec3& e
 // kernel's node records.  acc / rej equal "class > 0" / "class < 0" of rt_node_slab_class; neither = undecided.
 // (tc - T = -(T - tc) exactly, and max3(-a,-b,-c) > E <=> min3(a,b,c) < -E; a NaN can only come from an infinite
 // plane distance, which makes E infinite and both comparisons false.)
-RT_HD void rt_node_slab_fast(float lox, float hix, float loy, float hiy, float loz, float hiz, const RtVec3& e, const RtVec3& inv,
-                             float T, bool& acc, bool& rej) {
-  const float x0 = (lox - e.x) * inv.x, x1 = (hix - e.x) * inv.x;
-  const float y0 = (loy - e.y) * inv.y, y1 = (hiy - e.y) * inv.y;
-  const float z0 = (loz - e.z) * inv.z, z1 = (hiz - e.z) * inv.z;
-  const float nx = fminf(x0, x1), fx = fmaxf(x0, x1), ny = fminf(y0, y1), fy = fmaxf(y0, y1), nz = fminf(z0, z1), fz = fmaxf(z0, z1);
+RT_HD void rt_node_slab_sorted(float nx, float fx, float ny, float fy, float nz, float fz, float T, bool& acc, bool& rej) {
   const float tN = rt_max3(nx, ny, nz), tN2 = rt_med3(nx, ny, nz);
   const float tF = rt_min3(fx, fy, fz), tF2 = rt_med3(fx, fy, fz);
   const float M = fmaxf(rt_max3(fx, fy, fz), -rt_min3(nx, ny, nz));   // = max |t| over the six planes, as near <= far per axis
@@ -378,6 +373,62 @@ RT_HD void rt_node_slab_fast(float lox, float hix, float loy, float hiy, float l
   const float x = T - tc;
   acc = fminf(rt_min3(x, gap, span), tc) > E;
   rej = rt_min3(span, tF, x) < -E;
+}
+RT_HD void rt_node_slab_fast(float lox, float hix, float loy, float hiy, float loz, float hiz, const RtVec3& e, const RtVec3& inv,
+                             float T, bool& acc, bool& rej) {
+  const float x0 = (lox - e.x) * inv.x, x1 = (hix - e.x) * inv.x;
+  const float y0 = (loy - e.y) * inv.y, y1 = (hiy - e.y) * inv.y;
+  const float z0 = (loz - e.z) * inv.z, z1 = (hiz - e.z) * inv.z;
+  rt_node_slab_sorted(fminf(x0, x1), fmaxf(x0, x1), fminf(y0, y1), fmaxf(y0, y1), fminf(z0, z1), fmaxf(z0, z1), T, acc, rej);
+}
+// The same again when the caller already knows which plane of each axis is the near one (n*: the plane the ray meets
+// first, i.e. the low one for a positive direction component): (plane - e) * inv is monotone in the plane, so the two
+// products come out ordered and min / max are not needed.  With an infinite inv a product can be NaN where min / max
+// would have dropped it; E is infinite then and both answers are "no" either way.
+RT_HD void rt_node_slab_presorted(float nxp, float fxp, float nyp, float fyp, float nzp, float fzp, const RtVec3& e, const RtVec3& inv,
+                                  float T, bool& acc, bool& rej) {
+  rt_node_slab_sorted((nxp - e.x) * inv.x, (fxp - e.x) * inv.x, (nyp - e.y) * inv.y, (fyp - e.y) * inv.y,
+                      (nzp - e.z) * inv.z, (fzp - e.z) * inv.z, T, acc, rej);
+}
+
+// The same classification for a ray whose zero direction components are known at compile time (Z* = that component
+// is exactly zero; at least one is not).  Such an axis takes no part in the slab arithmetic; it only asks where the
+// origin lies between the two planes (rt_zero_axis, written as comparisons: with A = e - lo and B = hi - e,
+// strictly inside <=> 0 < min(A,B) and max(A,B) < side; outside for both conventions <=> (A < 0 and B > side) or
+// (B < 0 and A > side)).  acc / rej equal "class > 0" / "class < 0" of rt_node_slab_class for such a ray.
+template <bool ZX, bool ZY, bool ZZ>
+RT_HD void rt_node_slab_zero(float lox, float hix, float loy, float hiy, float loz, float hiz, const RtVec3& e, const RtVec3& inv,
+                             float T, bool& acc, bool& rej) {
+  static_assert(!(ZX && ZY && ZZ), "a direction has a non-zero component");
+  const float side = hix - lox;
+  const float lo[3] = {lox, loy, loz}, hi[3] = {hix, hiy, hiz}, ev[3] = {e.x, e.y, e.z}, iv[3] = {inv.x, inv.y, inv.z};
+  const bool Z[3] = {ZX, ZY, ZZ};
+  float n[2] = {0.f, 0.f}, f[2] = {0.f, 0.f};
+  int K = 0;
+  bool in_all = true, out_any = false;
+  for (int k = 0; k < 3; k++) {
+    if (Z[k]) {
+      const float A = ev[k] - lo[k], B = hi[k] - ev[k];
+      in_all = (int)in_all & (int)(fminf(A, B) > 0.f) & (int)(fmaxf(A, B) < side);
+      out_any = (int)out_any | ((int)(A < 0.f) & (int)(B > side)) | ((int)(B < 0.f) & (int)(A > side));
+    } else {
+      const float t0 = (lo[k] - ev[k]) * iv[k], t1 = (hi[k] - ev[k]) * iv[k];
+      n[K] = fminf(t0, t1); f[K] = fmaxf(t0, t1); K++;
+    }
+  }
+  const bool two = K == 2;
+  const float tN = two ? fmaxf(n[0], n[1]) : n[0], tN2 = fminf(n[0], n[1]);
+  const float tF = two ? fminf(f[0], f[1]) : f[0], tF2 = fmaxf(f[0], f[1]);
+  const float M = two ? fmaxf(tF2, -tN2) : fmaxf(f[0], -n[0]);
+  const float E = RT_SLAB_EPS * (M + T);
+  const float span = tF - tN;
+  const bool front = tN > 0.f;
+  const float tc = front ? tN : tF;
+  const float x = T - tc;
+  float a = fminf(x, span);
+  if (two) a = fminf(a, front ? tN - tN2 : tF2 - tF);
+  rej = (rt_min3(span, tF, x) < -E) | out_any;
+  acc = (fminf(a, tc) > E) & in_all & !rej;
 }
 
 // Same classification as two predicates (accepted / undecided), the form the wave kernel ballots.

@@ -19,7 +19,7 @@
 #include "../include/rt_amd.h"
 #include "../raytracer_amd/csrc/rt_math.h"
 
-static uint64_t n_node = 0, n_tri = 0, n_bad = 0, n_cand = 0, n_acc = 0, n_zero = 0, n_amb = 0;
+static uint64_t n_node = 0, n_tri = 0, n_bad = 0, n_cand = 0, n_acc = 0, n_zero = 0, n_amb = 0, n_zero_axis = 0;
 
 static bool check_node(const RtVec3& ini, const RtVec3& end, const RtVec3& e, const RtVec3& d, float T) {
   const bool lit = rt_node_accept_literal(ini, end, e, d, T);
@@ -36,11 +36,35 @@ static bool check_node(const RtVec3& ini, const RtVec3& end, const RtVec3& e, co
     const bool zx = d.x == 0.f, zy = d.y == 0.f, zz = d.z == 0.f;
     const int cls = rt_node_slab_class(lo, hi, e, inv, T, zx | zy | zz, zx, zy, zz);
     if (cls == 0) n_amb++;
+    if ((zx | zy | zz) && !(zx & zy & zz)) {   // the forms specialised on the zero pattern
+      bool za = false, zr = false;
+      const int zp = (zx ? 1 : 0) | (zy ? 2 : 0) | (zz ? 4 : 0);
+      switch (zp) {
+        case 1: rt_node_slab_zero<true, false, false>(lo.x, hi.x, lo.y, hi.y, lo.z, hi.z, e, inv, T, za, zr); break;
+        case 2: rt_node_slab_zero<false, true, false>(lo.x, hi.x, lo.y, hi.y, lo.z, hi.z, e, inv, T, za, zr); break;
+        case 3: rt_node_slab_zero<true, true, false>(lo.x, hi.x, lo.y, hi.y, lo.z, hi.z, e, inv, T, za, zr); break;
+        case 4: rt_node_slab_zero<false, false, true>(lo.x, hi.x, lo.y, hi.y, lo.z, hi.z, e, inv, T, za, zr); break;
+        case 5: rt_node_slab_zero<true, false, true>(lo.x, hi.x, lo.y, hi.y, lo.z, hi.z, e, inv, T, za, zr); break;
+        case 6: rt_node_slab_zero<false, true, true>(lo.x, hi.x, lo.y, hi.y, lo.z, hi.z, e, inv, T, za, zr); break;
+      }
+      n_zero_axis++;
+      if (za != (cls > 0) || zr != (cls < 0)) {
+        if (n_bad < 10) printf("SLAB ZERO-PATTERN/GENERAL DIFFER pattern %d cls %d special %d %d\n", zp, cls, (int)za, (int)zr);
+        n_bad++;
+      }
+    }
     if (!(zx | zy | zz)) {
       bool fa, fr;
       rt_node_slab_fast(lo.x, hi.x, lo.y, hi.y, lo.z, hi.z, e, inv, T, fa, fr);
       if (fa != (cls > 0) || fr != (cls < 0)) {
         if (n_bad < 10) printf("SLAB FAST/GENERAL DIFFER cls %d fast %d %d\n", cls, (int)fa, (int)fr);
+        n_bad++;
+      }
+      bool pa, pr;   // planes handed over in near / far order by the direction signs
+      rt_node_slab_presorted(d.x < 0 ? hi.x : lo.x, d.x < 0 ? lo.x : hi.x, d.y < 0 ? hi.y : lo.y, d.y < 0 ? lo.y : hi.y,
+                             d.z < 0 ? hi.z : lo.z, d.z < 0 ? lo.z : hi.z, e, inv, T, pa, pr);
+      if (pa != fa || pr != fr) {
+        if (n_bad < 10) printf("SLAB PRESORTED/FAST DIFFER %d %d vs %d %d\n", (int)pa, (int)pr, (int)fa, (int)fr);
         n_bad++;
       }
     }
@@ -142,7 +166,7 @@ static int run_scene(int ac, char** av) {
       trace(T, {P.x + ls[k].x * 0.001f, P.y + ls[k].y * 0.001f, P.z + ls[k].z * 0.001f}, ls[k], sh);
     }
   }
-  printf("checked %llu %llu mismatches %llu candidates %llu score_zero %llu slab_undecided %llu\n", (unsigned long long)n_node, (unsigned long long)n_tri, (unsigned long long)n_bad, (unsigned long long)n_cand, (unsigned long long)n_zero, (unsigned long long)n_amb);
+  printf("checked %llu %llu mismatches %llu candidates %llu score_zero %llu slab_undecided %llu zero_axis_tests %llu\n", (unsigned long long)n_node, (unsigned long long)n_tri, (unsigned long long)n_bad, (unsigned long long)n_cand, (unsigned long long)n_zero, (unsigned long long)n_amb, (unsigned long long)n_zero_axis);
   return n_bad ? 1 : 0;
 }
 
@@ -185,7 +209,7 @@ static int run_random(int ac, char** av) {
     }
     check_node(ini, end, e, d, T);
   }
-  printf("checked %llu %llu mismatches %llu accepted %llu score_zero %llu slab_undecided %llu\n", (unsigned long long)n_node, (unsigned long long)n_tri, (unsigned long long)n_bad, (unsigned long long)n_acc, (unsigned long long)n_zero, (unsigned long long)n_amb);
+  printf("checked %llu %llu mismatches %llu accepted %llu score_zero %llu slab_undecided %llu zero_axis_tests %llu\n", (unsigned long long)n_node, (unsigned long long)n_tri, (unsigned long long)n_bad, (unsigned long long)n_acc, (unsigned long long)n_zero, (unsigned long long)n_amb, (unsigned long long)n_zero_axis);
   return n_bad ? 1 : 0;
 }
 
