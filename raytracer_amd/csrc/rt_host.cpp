@@ -720,7 +720,8 @@ void load_scene_into(rt_scene& sc, const std::string& scene_path, const std::str
     for (size_t r = 0; r < sc.leaf_refs.size(); r++) {
       const RtTriGeom& g = sc.tri_geom[sc.leaf_refs[r]];
       RtTriLeaf& t = sc.tri_leaf[r];
-      for (int k = 0; k < 3; k++) { t.v0[k] = g.v0[k]; t.e1[k] = g.e1[k]; t.e2[k] = g.e2[k]; }
+      for (int k = 0; k < 3; k++) { t.v0[k] = g.v0[k]; t.e1[k] = g.e1[k]; }
+      t.e2xy[0] = g.e2[0]; t.e2xy[1] = g.e2[1]; t.e2yz[0] = g.e2[1]; t.e2yz[1] = g.e2[2]; t.e2zx[0] = g.e2[2]; t.e2zx[1] = g.e2[0];
       t.id = sc.leaf_refs[r];
     }
     sc.nodes.push_back(RtNode{});   // pad; not counted in info.n_nodes

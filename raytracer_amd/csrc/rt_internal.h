@@ -69,8 +69,11 @@ struct RtWaveNode { float lohi[6]; int32_t first; uint32_t meta; };
 //   six operations of triangle.cu:118-120), then mesh index and two pads.
 struct RtTriGeom { float v0[3]; float e1[3]; float e2[3]; int32_t mesh; int32_t pad[2]; };
 
-// Leaf-ordered copy of the intersection record, 64 B = one 16-dword scalar load: v0, e1, e2, triangle id, pad.
-struct alignas(64) RtTriLeaf { float v0[3]; float e1[3]; float e2[3]; int32_t id; int32_t pad[6]; };
+// Leaf-ordered copy of the intersection record, 64 B, read with wave-uniform addresses into SGPRs.  The pairs that
+// the first stage of the triangle test multiplies with packed-fp32 instructions sit in even-aligned adjacent dwords, so
+// they are used straight from SGPR pairs (e2 is stored as its three cyclic pairs):
+//   v0.x v0.y v0.z id | e1.x e1.y e1.z - | e2.x e2.y e2.y e2.z | e2.z e2.x - -
+struct alignas(64) RtTriLeaf { float v0[3]; int32_t id; float e1[3]; int32_t pad0; float e2xy[2]; float e2yz[2]; float e2zx[2]; int32_t pad1[2]; };
 
 // Triangle shading record, 64 B, read once per closest hit: v1, v2 and the three vertex normals.
 struct RtTriShade { float v1[3]; float v2[3]; float n0[3]; float n1[3]; float n2[3]; float pad; };

@@ -28,6 +28,8 @@ struct WaveStack {
   uint32_t first, cur, mask_lo, mask_hi;   // index of child 0 of the branch, next child to test, lanes that entered it
 };
 
+typedef float v2f __attribute__((ext_vector_type(2)));   // two floats handled by one packed-fp32 instruction
+
 __device__ __forceinline__ uint32_t uni(uint32_t v) { return __builtin_amdgcn_readfirstlane(v); }
 __device__ __forceinline__ uint64_t uni64(uint64_t v) {
   return ((uint64_t)uni((uint32_t)(v >> 32)) << 32) | uni((uint32_t)v);
@@ -49,6 +51,8 @@ __device__ __forceinline__ void trace_wave(const float4* __restrict__ nodes, int
   if (!live) return;
   if (COUNT) tl.w[0]++;
   const RtVec3 inv = {1.f / d.x, 1.f / d.y, 1.f / d.z};   // only feeds the conservative classification
+  const RtVec3 c2 = {-d.x, -d.y, -d.z};                   // third column of the triangle solve (triangle.cu:118-120)
+  const v2f e_xy = {e.x, e.y}, c_zx = {c2.z, c2.x}, c_yz = {c2.y, c2.z}, c_yx = {c2.y, c2.x};
   const unsigned zmask = (d.x == 0.f ? 1u : 0u) | (d.y == 0.f ? 2u : 0u) | (d.z == 0.f ? 4u : 0u);
   const bool any_zero = (__builtin_amdgcn_ballot_w64(zmask != 0u) & live) != 0ull;
   // Zero components usually come from an axis-parallel directional light, the same for every ray of the wave: then the
@@ -179,24 +183,24 @@ __device__ __forceinline__ void trace_wave(const float4* __restrict__ nodes, int
       if (COUNT && ((acc_m >> lane) & 1ull)) { tl.leaf++; tl.tri += (uint32_t)count; }
       if (count == 0) continue;
       uint64_t changed_m = 0ull;
-      const float4* tp = tri_leaf + 4 * (size_t)first;
-      float4 g0 = tp[0], g1 = tp[1], g2 = tp[2];
-      for (int32_t k = 0; k < count; k++) {
-        tp += 4;
-        const float4 h0 = tp[0], h1 = tp[1], h2 = tp[2];   // next triangle of the leaf (or the pad record)
-        const RtVec3 v0 = {g0.x, g0.y, g0.z}, e1 = {g0.w, g1.x, g1.y}, e2 = {g1.z, g1.w, g2.x};
-        const int32_t tri_id = (int32_t)__float_as_uint(g2.y);
-        g0 = h0; g1 = h1; g2 = h2;
+      // One triangle: the record is in SGPRs (q0..q3 as laid out in RtTriLeaf), every lane of acc_m tests it.
+      auto test_triangle = [&](const float4& q0, const float4& q1, const float4& q2, const float4& q3) {
         if (COUNT) tl.w[4]++;
-        // stage 1: determinant and beta numerator (triangle.cu:117-131, first column of cofactors)
-        const RtVec3 b = {e.x - v0.x, e.y - v0.y, e.z - v0.z};
-        const RtVec3 c2 = {-d.x, -d.y, -d.z};
-        const float m00 = e2.y * c2.z - c2.y * e2.z;
-        const float m10 = -e2.x * c2.z + e2.z * c2.x;
-        const float m20 = e2.x * c2.y - e2.y * c2.x;
+        // stage 1: determinant and beta numerator (triangle.cu:117-131, first column of cofactors); the operations and
+        // their order are the reference's, paired two to an instruction
+        const v2f bxy = e_xy - v2f{q0.x, q0.y};
+        float bz = e.z - q0.z;
+        asm volatile("" : "+v"(bz));   // keeps this subtraction from being paired with the one that forms m20 (the pairing costs three moves)
+        const v2f p1 = v2f{q2.z, q2.w} * c_zx;          // e2.y c2.z , e2.z c2.x
+        const v2f p2 = v2f{q3.x, q3.y} * c_yz;          // e2.z c2.y , e2.x c2.z
+        const v2f m01 = p1 - p2;                        // m00 , m10
+        const v2f p3 = v2f{q2.x, q2.y} * c_yx;          // e2.x c2.y , e2.y c2.x
+        const float m20 = p3.x - p3.y;
+        const v2f qd = v2f{q1.x, q1.y} * m01;
+        const v2f qb = m01 * bxy;
         RtTriNum n;
-        n.det = e1.x * m00 + e1.y * m10 + e1.z * m20;
-        n.nb = m00 * b.x + m10 * b.y + m20 * b.z;
+        n.det = (qd.x + qd.y) + q1.z * m20;
+        n.nb = (qb.x + qb.y) + m20 * bz;
         const unsigned s = rt_bits(n.det) & 0x80000000u;
         const float ad = fabsf(n.det);
         const float nbs = rt_from_bits(rt_bits(n.nb) ^ s);
@@ -204,24 +208,27 @@ __device__ __forceinline__ void trace_wave(const float4* __restrict__ nodes, int
         uint64_t pass_m = __builtin_amdgcn_ballot_w64(nbs >= 0.f) & __builtin_amdgcn_ballot_w64(nbs <= ad) & acc_m;
 #ifdef RT_ABL_TRI2
         {   // ablation: stage 1 a second time
-          RtVec3 e_ = e; asm volatile("" : "+v"(e_.x), "+v"(e_.y), "+v"(e_.z));
-          const RtVec3 b_ = {e_.x - v0.x, e_.y - v0.y, e_.z - v0.z};
-          const float det_ = e1.x * m00 + e1.y * m10 + e1.z * m20;
-          const float nb_ = m00 * b_.x + m10 * b_.y + m20 * b_.z;
-          const float q_ = fminf(rt_from_bits(rt_bits(nb_) ^ (rt_bits(det_) & 0x80000000u)), fabsf(det_) - nb_);
-          asm volatile("" :: "v"(q_));
+          v2f e2_ = e_xy; asm volatile("" : "+v"(e2_));
+          const v2f b_ = e2_ - v2f{q0.x, q0.y};
+          const v2f r_ = m01 * b_;
+          const float nb_ = (r_.x + r_.y) + m20 * bz;
+          const v2f d_ = v2f{q1.x, q1.y} * m01;
+          const float det_ = (d_.x + d_.y) + q1.z * m20;
+          asm volatile("" :: "v"(nb_), "v"(det_));
         }
 #endif
-        if (!pass_m) continue;
+        if (!pass_m) return;
         if (COUNT) tl.w[5]++;
+        const RtVec3 e1 = {q1.x, q1.y, q1.z}, e2 = {q2.x, q2.y, q2.w};
+        const RtVec3 b = {bxy.x, bxy.y, bz};
         // stage 2: gamma numerator
-        const float m01 = -e1.y * c2.z + e1.z * c2.y;
+        const float m01s = -e1.y * c2.z + e1.z * c2.y;
         const float m11 = e1.x * c2.z - e1.z * c2.x;
         const float m21 = -e1.x * c2.y + e1.y * c2.x;
-        n.ng = m01 * b.x + m11 * b.y + m21 * b.z;
+        n.ng = m01s * b.x + m11 * b.y + m21 * b.z;
         const float ngs = rt_from_bits(rt_bits(n.ng) ^ s);
         pass_m &= __builtin_amdgcn_ballot_w64(ngs >= 0.f) & __builtin_amdgcn_ballot_w64(ngs <= ad);
-        if (!pass_m) continue;
+        if (!pass_m) return;
         if (COUNT) tl.w[6]++;
         // stage 3: t numerator; t > 0, and t clearly beyond the closest hit is rejected without dividing
         const float m02 = e1.y * e2.z - e1.z * e2.y;
@@ -230,13 +237,26 @@ __device__ __forceinline__ void trace_wave(const float4* __restrict__ nodes, int
         n.nt = m02 * b.x + m12 * b.y + m22 * b.z;
         const float nts = rt_from_bits(rt_bits(n.nt) ^ s);
         pass_m &= __builtin_amdgcn_ballot_w64(nts > 0.f) & __builtin_amdgcn_ballot_w64(nts <= (hit.t * ad) * 1.000001f);
-        if (!pass_m) continue;
+        if (!pass_m) return;
         if (COUNT) tl.w[7]++;
         if ((pass_m >> lane) & 1ull) {   // the reference's quotients decide (triangle.cu:131-137)
           float t, bet, gam;
-          if (rt_triangle_finish(n, hit.t, t, bet, gam)) { hit.t = t; hit.prim = tri_id; hit.bet = bet; hit.gam = gam; }
+          if (rt_triangle_finish(n, hit.t, t, bet, gam)) { hit.t = t; hit.prim = (int32_t)__float_as_uint(q0.w); hit.bet = bet; hit.gam = gam; }
         }
-        changed_m |= pass_m;   // a superset of the lanes whose t changed is enough: their bounds are simply refreshed
+        changed_m |= pass_m;   // a superset of the lanes whose t changed is enough
+      };
+      // The leaf's records are streamed through two register sets in turn, each refilled with the record after next
+      // while the other is being tested (both arrays end with a pad record, so reading one past the leaf is harmless).
+      const float4* tp = tri_leaf + 4 * (size_t)first;
+      float4 a0 = tp[0], a1 = tp[1], a2 = tp[2], a3 = tp[3];
+      for (int32_t k = count;;) {
+        const float4 b0 = tp[4], b1 = tp[5], b2 = tp[6], b3 = tp[7];
+        test_triangle(a0, a1, a2, a3);
+        if (--k == 0) break;
+        tp += 8;
+        a0 = tp[0]; a1 = tp[1]; a2 = tp[2]; a3 = tp[3];
+        test_triangle(b0, b1, b2, b3);
+        if (--k == 0) break;
       }
       if (changed_m) {
         const bool done = stop_t >= 0.f && hit.t < stop_t;
