@@ -88,20 +88,26 @@ __device__ __forceinline__ void trace_wave(const float4* __restrict__ nodes, int
     // a branch: on descent or ascent), so its latency hides behind the classification.
     float4 nx_a = {0, 0, 0, 0}, nx_b = {0, 0, 0, 0};
     { const uint32_t i = top_first + (uint32_t)__builtin_ctz(rem | 0x100u); nx_a = nodes[NS * i]; nx_b = nodes[NS * i + 1]; }
+    // `mine_m` = lanes that entered the current branch and are still undecided.  It only changes when the branch changes or
+    // a lane gets decided; whenever it becomes empty the branch is abandoned by clearing `rem`, so that the loop head has
+    // a single scalar test.
+    uint64_t mine_m = top_mask;
     for (;;) {
-      const uint64_t mine_m = top_mask & live;
-      if (rem == 0u || mine_m == 0ull) {   // branch exhausted, or every lane that entered it is decided
+      if (rem == 0u) {   // branch exhausted (or abandoned)
         if (sp == 0) break;
         sp--;
         top_first = __builtin_amdgcn_readlane(st.first, sp); rem = __builtin_amdgcn_readlane(st.cur, sp);
         top_mask = ((uint64_t)(uint32_t)__builtin_amdgcn_readlane(st.mask_hi, sp) << 32) | (uint32_t)__builtin_amdgcn_readlane(st.mask_lo, sp);
+        mine_m = top_mask & live;
+        if (mine_m == 0ull) { rem = 0u; continue; }
         const uint32_t i = top_first + (uint32_t)__builtin_ctz(rem);   // entries are only pushed with children left
         nx_a = nodes[NS * i]; nx_b = nodes[NS * i + 1];
         continue;
       }
       rem &= rem - 1u;
       const float4 na = nx_a, nb = nx_b;
-      if (rem != 0u) { const uint32_t i = top_first + (uint32_t)__builtin_ctz(rem); nx_a = nodes[NS * i]; nx_b = nodes[NS * i + 1]; }
+      // next sibling ("child 8" after the last one is the first record of the next block or the pad record)
+      { const uint32_t i = top_first + (uint32_t)__builtin_ctz(rem | 0x100u); const float4* rp = nodes + NS * i; nx_a = rp[0]; nx_b = rp[1]; }
       if (COUNT) { if (uni(__float_as_uint(nb.w)) != 0u) tl.w[1]++; if ((mine_m >> lane) & 1ull) tl.node++; }   // w[1]: iterations the plain variant also makes
       // conservative slab classification first; the exact test only where some lane is within rounding of a boundary
       uint64_t acc_m, und_m;
@@ -173,7 +179,7 @@ __device__ __forceinline__ void trace_wave(const float4* __restrict__ nodes, int
           st.mask_lo = slot ? (uint32_t)top_mask : st.mask_lo; st.mask_hi = slot ? (uint32_t)(top_mask >> 32) : st.mask_hi;
           sp++;
         }
-        top_first = first; rem = crem; top_mask = acc_m;
+        top_first = first; rem = crem; top_mask = acc_m; mine_m = acc_m;
         const uint32_t i = top_first + (uint32_t)__builtin_ctz(rem);
         nx_a = nodes[NS * i]; nx_b = nodes[NS * i + 1];
         continue;
@@ -262,6 +268,8 @@ __device__ __forceinline__ void trace_wave(const float4* __restrict__ nodes, int
         const bool done = stop_t >= 0.f && hit.t < stop_t;
         live &= ~__builtin_amdgcn_ballot_w64(done);
         if (!live) return;
+        mine_m = top_mask & live;
+        if (mine_m == 0ull) rem = 0u;   // nobody left in this branch
       }
     }
   }

@@ -396,23 +396,23 @@ RT_HD void rt_node_slab_presorted(float nxp, float fxp, float nyp, float fyp, fl
 // origin lies between the two planes (rt_zero_axis, written as comparisons: with A = e - lo and B = hi - e,
 // strictly inside <=> 0 < min(A,B) and max(A,B) < side; outside for both conventions <=> (A < 0 and B > side) or
 // (B < 0 and A > side)).  acc / rej equal "class > 0" / "class < 0" of rt_node_slab_class for such a ray.
+// dlo / dhi: the differences fl(lo - e) and fl(hi - e) per axis (the wave kernel forms them while the record is in its
+// scalar registers); A = e - lo is the exact negation of dlo.
 template <bool ZX, bool ZY, bool ZZ>
-RT_HD void rt_node_slab_zero(float lox, float hix, float loy, float hiy, float loz, float hiz, const RtVec3& e, const RtVec3& inv,
-                             float T, bool& acc, bool& rej) {
+RT_HD void rt_node_slab_zero_d(const float* dlo, const float* dhi, float side, const RtVec3& inv, float T, bool& acc, bool& rej) {
   static_assert(!(ZX && ZY && ZZ), "a direction has a non-zero component");
-  const float side = hix - lox;
-  const float lo[3] = {lox, loy, loz}, hi[3] = {hix, hiy, hiz}, ev[3] = {e.x, e.y, e.z}, iv[3] = {inv.x, inv.y, inv.z};
+  const float iv[3] = {inv.x, inv.y, inv.z};
   const bool Z[3] = {ZX, ZY, ZZ};
   float n[2] = {0.f, 0.f}, f[2] = {0.f, 0.f};
   int K = 0;
   bool in_all = true, out_any = false;
   for (int k = 0; k < 3; k++) {
     if (Z[k]) {
-      const float A = ev[k] - lo[k], B = hi[k] - ev[k];
+      const float A = -dlo[k], B = dhi[k];
       in_all = (int)in_all & (int)(fminf(A, B) > 0.f) & (int)(fmaxf(A, B) < side);
       out_any = (int)out_any | ((int)(A < 0.f) & (int)(B > side)) | ((int)(B < 0.f) & (int)(A > side));
     } else {
-      const float t0 = (lo[k] - ev[k]) * iv[k], t1 = (hi[k] - ev[k]) * iv[k];
+      const float t0 = dlo[k] * iv[k], t1 = dhi[k] * iv[k];
       n[K] = fminf(t0, t1); f[K] = fmaxf(t0, t1); K++;
     }
   }
@@ -429,6 +429,12 @@ RT_HD void rt_node_slab_zero(float lox, float hix, float loy, float hiy, float l
   if (two) a = fminf(a, front ? tN - tN2 : tF2 - tF);
   rej = (rt_min3(span, tF, x) < -E) | out_any;
   acc = (fminf(a, tc) > E) & in_all & !rej;
+}
+template <bool ZX, bool ZY, bool ZZ>
+RT_HD void rt_node_slab_zero(float lox, float hix, float loy, float hiy, float loz, float hiz, const RtVec3& e, const RtVec3& inv,
+                             float T, bool& acc, bool& rej) {
+  const float dlo[3] = {lox - e.x, loy - e.y, loz - e.z}, dhi[3] = {hix - e.x, hiy - e.y, hiz - e.z};
+  rt_node_slab_zero_d<ZX, ZY, ZZ>(dlo, dhi, hix - lox, inv, T, acc, rej);
 }
 
 // Same classification as two predicates (accepted / undecided), the form the wave kernel ballots.
