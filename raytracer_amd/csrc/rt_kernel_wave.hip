@@ -104,27 +104,38 @@ __device__ __forceinline__ void trace_wave(const float4* __restrict__ nodes, int
         nx_a = nodes[NS * i]; nx_b = nodes[NS * i + 1];
         continue;
       }
-      rem &= rem - 1u;
-      const float4 na = nx_a, nb = nx_b;
-      // next sibling ("child 8" after the last one is the first record of the next block or the pad record)
-      { const uint32_t i = top_first + (uint32_t)__builtin_ctz(rem | 0x100u); const float4* rp = nodes + NS * i; nx_a = rp[0]; nx_b = rp[1]; }
-      if (COUNT) { if (uni(__float_as_uint(nb.w)) != 0u) tl.w[1]++; if ((mine_m >> lane) & 1ull) tl.node++; }   // w[1]: iterations the plain variant also makes
-      // conservative slab classification first; the exact test only where some lane is within rounding of a boundary
+      float4 na, nb;
       uint64_t acc_m, und_m;
+      // conservative slab classification first; the exact test only where some lane is within rounding of a boundary
       if (presorted) {
-        bool c_acc, c_rej;
-        rt_node_slab_presorted(na.x, na.y, na.z, na.w, nb.x, nb.y, e, inv, hit.t, c_acc, c_rej);
+        // Siblings are scanned in a tight loop until one is accepted by some lane (or needs the exact test): about two
+        // node tests in three end in "no lane", and those never leave this loop.
+        for (;;) {
+          rem &= rem - 1u;
+          na = nx_a; nb = nx_b;
+          // next sibling ("child 8" after the last one is the first record of the next block or the pad record)
+          { const uint32_t i = top_first + (uint32_t)__builtin_ctz(rem | 0x100u); const float4* rp = nodes + NS * i; nx_a = rp[0]; nx_b = rp[1]; }
+          if (COUNT) { if (uni(__float_as_uint(nb.w)) != 0u) tl.w[1]++; if ((mine_m >> lane) & 1ull) tl.node++; }   // w[1]: iterations the plain variant also makes
+          bool c_acc, c_rej;
+          rt_node_slab_presorted(na.x, na.y, na.z, na.w, nb.x, nb.y, e, inv, hit.t, c_acc, c_rej);
 #ifdef RT_ABL_NODE2
-        {   // ablation: evaluate the classification a second time on values the compiler cannot fold
-          float t2 = hit.t; asm volatile("" : "+v"(t2));
-          bool a2, r2;
-          rt_node_slab_presorted(na.x, na.y, na.z, na.w, nb.x, nb.y, e, inv, t2, a2, r2);
-          asm volatile("" :: "s"(__builtin_amdgcn_ballot_w64(a2)), "s"(__builtin_amdgcn_ballot_w64(r2)));
-        }
+          {   // ablation: evaluate the classification a second time on values the compiler cannot fold
+            float t2 = hit.t; asm volatile("" : "+v"(t2));
+            bool a2, r2;
+            rt_node_slab_presorted(na.x, na.y, na.z, na.w, nb.x, nb.y, e, inv, t2, a2, r2);
+            asm volatile("" :: "s"(__builtin_amdgcn_ballot_w64(a2)), "s"(__builtin_amdgcn_ballot_w64(r2)));
+          }
 #endif
-        acc_m = __builtin_amdgcn_ballot_w64(c_acc) & mine_m;
-        und_m = mine_m & ~(acc_m | __builtin_amdgcn_ballot_w64(c_rej));
-      } else if (!any_zero) {
+          acc_m = __builtin_amdgcn_ballot_w64(c_acc) & mine_m;
+          und_m = mine_m & ~(acc_m | __builtin_amdgcn_ballot_w64(c_rej));
+          if ((acc_m | und_m) != 0ull || rem == 0u) break;
+        }
+      } else {
+      rem &= rem - 1u;
+      na = nx_a; nb = nx_b;
+      { const uint32_t i = top_first + (uint32_t)__builtin_ctz(rem | 0x100u); const float4* rp = nodes + NS * i; nx_a = rp[0]; nx_b = rp[1]; }
+      if (COUNT) { if (uni(__float_as_uint(nb.w)) != 0u) tl.w[1]++; if ((mine_m >> lane) & 1ull) tl.node++; }
+      if (!any_zero) {
         bool c_acc, c_rej;
         rt_node_slab_fast(na.x, na.y, na.z, na.w, nb.x, nb.y, e, inv, hit.t, c_acc, c_rej);
         acc_m = __builtin_amdgcn_ballot_w64(c_acc) & mine_m;
@@ -146,6 +157,7 @@ __device__ __forceinline__ void trace_wave(const float4* __restrict__ nodes, int
         rt_node_slab_class2({na.x, na.z, nb.x}, {na.y, na.w, nb.y}, e, inv, hit.t, true, zmask, c_acc, c_und);
         acc_m = __builtin_amdgcn_ballot_w64(c_acc) & mine_m;
         und_m = __builtin_amdgcn_ballot_w64(c_und) & mine_m;
+      }
       }
       if (und_m) {
         if (COUNT) tl.w[2]++;
