@@ -80,7 +80,8 @@ static int launch_render(rt_dscene* d, const RowMap& rows, uint8_t* d_rgb, int32
                          unsigned flags, rt_stats* stats) {
   hipStream_t stream = (hipStream_t)stream_;
   HIP_TRY(hipSetDevice(d->device));
-  HIP_TRY(hipMemsetAsync(d->d_counters, 0, RT_COUNTER_COPIES * RT_COUNTER_STRIDE * sizeof(unsigned long long), stream));
+  // the counters are only read back for a caller that passes an rt_stats: no need to clear them for anybody else
+  if (stats) HIP_TRY(hipMemsetAsync(d->d_counters, 0, RT_COUNTER_COPIES * RT_COUNTER_STRIDE * sizeof(unsigned long long), stream));
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
   const bool timed = (flags & RT_RENDER_TIME) != 0;
   if (timed) { HIP_TRY(hipEventCreate(&ev0)); HIP_TRY(hipEventCreate(&ev1)); HIP_TRY(hipEventRecord(ev0, stream)); }
