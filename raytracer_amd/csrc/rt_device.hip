@@ -2,6 +2,7 @@
 #include <hip/hip_runtime.h>
 
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -76,7 +77,7 @@ extern "C" int rt_scene_upload(const rt_scene* s, int device, rt_dscene** out) {
   return RT_OK;
 }
 
-static int launch_render(rt_dscene* d, const RowMap& rows, uint8_t* d_rgb, int32_t* d_ids, float* d_t, void* stream_,
+static int launch_render(rt_dscene* d, RowMap rows, uint8_t* d_rgb, int32_t* d_ids, float* d_t, void* stream_,
                          unsigned flags, rt_stats* stats) {
   hipStream_t stream = (hipStream_t)stream_;
   HIP_TRY(hipSetDevice(d->device));
@@ -86,6 +87,17 @@ static int launch_render(rt_dscene* d, const RowMap& rows, uint8_t* d_rgb, int32
   const bool timed = (flags & RT_RENDER_TIME) != 0;
   if (timed) { HIP_TRY(hipEventCreate(&ev0)); HIP_TRY(hipEventCreate(&ev1)); HIP_TRY(hipEventRecord(ev0, stream)); }
   if (rows.n_local > 0) {
+    if (!(flags & RT_RENDER_LITERAL)) {
+      // Small frames are cut into 4x4 tiles where that was measured to pay: heavy meshes when the 8x8 tiles do not even
+      // fill the chip's wave slots (256 CUs x 4 SIMDs x 5), and scenes with mirrors or glass over a mesh, whose frame time
+      // is the longest chain of dependent walks of one tile, up to about 720p.  (meshDragon 512x512: 1.50 -> 1.18 ms,
+      // glass bunny 512x512: 7.8 -> 4.8 ms; light scenes and larger frames are faster on 8x8 tiles.)
+      const long tiles = ((long)(d->view.cam.width + 7) / 8) * ((rows.n_local + 7) / 8);
+      static const int forced = getenv("RT_AMD_TILE") ? atoi(getenv("RT_AMD_TILE")) : 0;   // 4 or 8: measurements
+      const bool mesh = d->info.n_triangles > 0;
+      rows.small = forced ? (forced == 4)
+                          : ((d->info.n_triangles >= 20000 && tiles < 5120) || (d->info.has_bounce_materials && mesh && tiles < 16384));
+    }
     const bool bounce = d->info.has_bounce_materials != 0, count = (flags & RT_RENDER_COUNT_TESTS) != 0;
     if (flags & RT_RENDER_LITERAL) rt_launch_lane_kernel(d->view, rows, bounce, count, d_rgb, d_ids, d_t, d->d_counters, stats != nullptr, stream);
     else rt_launch_wave_kernel(d->view, rows, bounce, count, d_rgb, d_ids, d_t, d->d_counters, stats != nullptr, stream);

@@ -371,16 +371,21 @@ __global__ __launch_bounds__(RT_BLOCK, BOUNCE ? RT_WAVES_PER_SIMD_BOUNCE : RT_WA
   // Pixel of a thread: wave w of the block owns the 8x8 tile (w & 1, w >> 1) of the block's 16x16 pixels.  The
   // coordinates are needed at the start, after the primary ray and at the end; they are derived again each time
   // from an opaque copy of the thread index, so that none of them occupies a register (or a spill slot) in between.
-  struct Pixel { int col, lrow, row, orow; bool valid; };
+  struct Pixel { int col, lrow, row, orow; bool valid; };   // (derived per use, see below)
   auto pixel_of = [&](int t) {
     asm volatile("" : "+v"(t));
     const int w = t >> 6, l = t & 63;
     Pixel p;
-    p.col = blockIdx.x * RT_TILE_W + (w & 1) * 8 + (l & 7);
-    p.lrow = blockIdx.y * RT_TILE_H + (w >> 1) * 8 + (l >> 3);
+    if (rows.small) {
+      p.col = blockIdx.x * (RT_TILE_W / 2) + (w & 1) * 4 + (l & 3);
+      p.lrow = blockIdx.y * (RT_TILE_H / 2) + (w >> 1) * 4 + ((l >> 2) & 3);
+    } else {
+      p.col = blockIdx.x * RT_TILE_W + (w & 1) * 8 + (l & 7);
+      p.lrow = blockIdx.y * RT_TILE_H + (w >> 1) * 8 + (l >> 3);
+    }
     p.row = rows.row0 + (p.lrow / rows.band_rows) * rows.band_stride + p.lrow % rows.band_rows;
     p.orow = rows.compact ? p.lrow : p.row;
-    p.valid = p.col < W && p.lrow < rows.n_local && p.row < H;
+    p.valid = p.col < W && p.lrow < rows.n_local && p.row < H && (!rows.small || l < 16);
     return p;
   };
   Tally tl = {0, 0, 0, 0, 0, 0, 0, {0, 0, 0, 0, 0, 0, 0, 0}};
@@ -596,11 +601,11 @@ __global__ __launch_bounds__(RT_BLOCK, BOUNCE ? RT_WAVES_PER_SIMD_BOUNCE : RT_WA
     q[k] = v < 0.f ? (uint8_t)0 : (uint8_t)(int)v;
   }
   const Pixel pxe = pixel_of(tid);
-  const int wave = (pxe.lrow >> 3 & 1) * 2 + (pxe.col >> 3 & 1);   // = tid >> 6
+  int wave = tid; asm volatile("" : "+v"(wave)); wave >>= 6;
   if (pxe.valid) tl.rays++;   // the primary ray
   const int col0 = pxe.col & ~7, lrow0 = pxe.lrow & ~7;   // tile origin (wave-uniform)
   const int last_row = rows.row0 + ((lrow0 + 7) / rows.band_rows) * rows.band_stride + (lrow0 + 7) % rows.band_rows;
-  const bool whole = (W & 3) == 0 && col0 + 8 <= W && lrow0 + 8 <= rows.n_local && last_row < H &&
+  const bool whole = !rows.small && (W & 3) == 0 && col0 + 8 <= W && lrow0 + 8 <= rows.n_local && last_row < H &&
                      (lrow0 / rows.band_rows) == ((lrow0 + 7) / rows.band_rows);   // wave-uniform
   if (whole) {
     uint8_t* pk = (uint8_t*)pack[wave];
@@ -634,7 +639,8 @@ __global__ __launch_bounds__(RT_BLOCK, BOUNCE ? RT_WAVES_PER_SIMD_BOUNCE : RT_WA
 
 void rt_launch_wave_kernel(const RtDeviceView& V, const RowMap& rows, bool bounce, bool count, uint8_t* rgb, int32_t* ids,
                            float* ts, unsigned long long* counters, bool tally, hipStream_t stream) {
-  const dim3 grid((V.cam.width + RT_TILE_W - 1) / RT_TILE_W, (rows.n_local + RT_TILE_H - 1) / RT_TILE_H), block(RT_BLOCK);
+  const int tw = rows.small ? RT_TILE_W / 2 : RT_TILE_W, th = rows.small ? RT_TILE_H / 2 : RT_TILE_H;
+  const dim3 grid((V.cam.width + tw - 1) / tw, (rows.n_local + th - 1) / th), block(RT_BLOCK);
 #define LAUNCH(B, C)                                                                                                             \
   hipLaunchKernelGGL((render_wave<B, C>), grid, block, 0, stream, V.cam, rows, V.wnodes, V.tri_leaf, V.tri_geom, V.tri_shade,     \
                      V.spheres, V.lights, V.materials, V.mat_index, V.mesh_mat_first, V.mesh_mat_count, V.n_spheres, V.n_lights, \
