@@ -118,14 +118,6 @@ __device__ __forceinline__ void trace_wave(const float4* __restrict__ nodes, int
           if (COUNT) { if (uni(__float_as_uint(nb.w)) != 0u) tl.w[1]++; if ((mine_m >> lane) & 1ull) tl.node++; }   // w[1]: iterations the plain variant also makes
           bool c_acc, c_rej;
           rt_node_slab_presorted(na.x, na.y, na.z, na.w, nb.x, nb.y, e, inv, hit.t, c_acc, c_rej);
-#ifdef RT_ABL_NODE2
-          {   // ablation: evaluate the classification a second time on values the compiler cannot fold
-            float t2 = hit.t; asm volatile("" : "+v"(t2));
-            bool a2, r2;
-            rt_node_slab_presorted(na.x, na.y, na.z, na.w, nb.x, nb.y, e, inv, t2, a2, r2);
-            asm volatile("" :: "s"(__builtin_amdgcn_ballot_w64(a2)), "s"(__builtin_amdgcn_ballot_w64(r2)));
-          }
-#endif
           acc_m = __builtin_amdgcn_ballot_w64(c_acc) & mine_m;
           und_m = mine_m & ~(acc_m | __builtin_amdgcn_ballot_w64(c_rej));
           if ((acc_m | und_m) != 0ull || rem == 0u) break;
@@ -224,17 +216,6 @@ __device__ __forceinline__ void trace_wave(const float4* __restrict__ nodes, int
         const float nbs = rt_from_bits(rt_bits(n.nb) ^ s);
         // 0 <= beta <= 1  <=>  0 <= nbs <= |det|   (det == 0 cannot survive stage 3: 0 < nts <= 0)
         uint64_t pass_m = __builtin_amdgcn_ballot_w64(nbs >= 0.f) & __builtin_amdgcn_ballot_w64(nbs <= ad) & acc_m;
-#ifdef RT_ABL_TRI2
-        {   // ablation: stage 1 a second time
-          v2f e2_ = e_xy; asm volatile("" : "+v"(e2_));
-          const v2f b_ = e2_ - v2f{q0.x, q0.y};
-          const v2f r_ = m01 * b_;
-          const float nb_ = (r_.x + r_.y) + m20 * bz;
-          const v2f d_ = v2f{q1.x, q1.y} * m01;
-          const float det_ = (d_.x + d_.y) + q1.z * m20;
-          asm volatile("" :: "v"(nb_), "v"(det_));
-        }
-#endif
         if (!pass_m) return;
         if (COUNT) tl.w[5]++;
         const RtVec3 e1 = {q1.x, q1.y, q1.z}, e2 = {q2.x, q2.y, q2.w};

@@ -1,3 +1,6 @@
+#!/usr/bin/env python3
+"""Kernel time, ray counts and wave-level iteration counts of mesh scenes at 512x512 for ray depths 0..3:
+shows how much of a frame's time the bounce rays of a few tiles take."""
 import sys; sys.path.insert(0,'.')
 import raytracer_amd as rt
 for scene in ["meshTransparentBunny","meshTorus","meshMedBunny"]:

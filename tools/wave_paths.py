@@ -1,3 +1,6 @@
+#!/usr/bin/env python3
+"""Wave-level iteration counts of the instrumented kernel on the headline frame (how often each code path of the
+traversal runs); run from the repository root."""
 import sys
 sys.path.insert(0,'.')
 import raytracer_amd as rt
