@@ -79,6 +79,12 @@ __device__ __forceinline__ void trace_wave(const float4* __restrict__ nodes, int
     // child c, lowest first = the reference's order 0..7).  Empty leaves are left out of `rem` from the start: testing
     // one has no effect on any result, only on the node-test count, so the instrumented variant keeps them.
     constexpr uint32_t NS = 2;   // float4 per node record
+    // The node array is read through the constant address space: such loads are scalar loads whatever the compiler can
+    // or cannot prove about stores elsewhere, which allows keeping a running pointer to the current branch's children.
+    typedef float f4 __attribute__((ext_vector_type(4)));
+    typedef const __attribute__((address_space(4))) f4* cnode_ptr;
+    const cnode_ptr cnodes = (cnode_ptr)(uintptr_t)nodes;
+    auto rec = [](cnode_ptr p) { const f4 v = *p; return float4{v.x, v.y, v.z, v.w}; };
     uint32_t top_first = uni(__float_as_uint(nodes[1].z));   // the root is entered without a test (ray.cu:36-38)
     uint32_t rem = COUNT ? 0xffu : (uni(__float_as_uint(nodes[1].w)) & 0xffu);
     uint64_t top_mask = live;
@@ -87,7 +93,8 @@ __device__ __forceinline__ void trace_wave(const float4* __restrict__ nodes, int
     // always requested as soon as it is known (next sibling: before the current child is classified; first child of
     // a branch: on descent or ascent), so its latency hides behind the classification.
     float4 nx_a = {0, 0, 0, 0}, nx_b = {0, 0, 0, 0};
-    { const uint32_t i = top_first + (uint32_t)__builtin_ctz(rem | 0x100u); nx_a = nodes[NS * i]; nx_b = nodes[NS * i + 1]; }
+    cnode_ptr blk = cnodes + NS * top_first;   // records of the current branch's children
+    { const uint32_t c = (uint32_t)__builtin_ctz(rem | 0x100u); nx_a = rec(blk + NS * c); nx_b = rec(blk + NS * c + 1); }
     // `mine_m` = lanes that entered the current branch and are still undecided.  It only changes when the branch changes or
     // a lane gets decided; whenever it becomes empty the branch is abandoned by clearing `rem`, so that the loop head has
     // a single scalar test.
@@ -100,8 +107,9 @@ __device__ __forceinline__ void trace_wave(const float4* __restrict__ nodes, int
         top_mask = ((uint64_t)(uint32_t)__builtin_amdgcn_readlane(st.mask_hi, sp) << 32) | (uint32_t)__builtin_amdgcn_readlane(st.mask_lo, sp);
         mine_m = top_mask & live;
         if (mine_m == 0ull) { rem = 0u; continue; }
-        const uint32_t i = top_first + (uint32_t)__builtin_ctz(rem);   // entries are only pushed with children left
-        nx_a = nodes[NS * i]; nx_b = nodes[NS * i + 1];
+        blk = cnodes + NS * top_first;
+        const uint32_t c = (uint32_t)__builtin_ctz(rem);   // entries are only pushed with children left
+        nx_a = rec(blk + NS * c); nx_b = rec(blk + NS * c + 1);
         continue;
       }
       float4 na, nb;
@@ -114,7 +122,7 @@ __device__ __forceinline__ void trace_wave(const float4* __restrict__ nodes, int
           rem &= rem - 1u;
           na = nx_a; nb = nx_b;
           // next sibling ("child 8" after the last one is the first record of the next block or the pad record)
-          { const uint32_t i = top_first + (uint32_t)__builtin_ctz(rem | 0x100u); const float4* rp = nodes + NS * i; nx_a = rp[0]; nx_b = rp[1]; }
+          { const uint32_t c = (uint32_t)__builtin_ctz(rem | 0x100u); nx_a = rec(blk + NS * c); nx_b = rec(blk + NS * c + 1); }
           if (COUNT) { if (uni(__float_as_uint(nb.w)) != 0u) tl.w[1]++; if ((mine_m >> lane) & 1ull) tl.node++; }   // w[1]: iterations the plain variant also makes
           bool c_acc, c_rej;
           rt_node_slab_presorted(na.x, na.y, na.z, na.w, nb.x, nb.y, e, inv, hit.t, c_acc, c_rej);
@@ -125,7 +133,7 @@ __device__ __forceinline__ void trace_wave(const float4* __restrict__ nodes, int
       } else {
       rem &= rem - 1u;
       na = nx_a; nb = nx_b;
-      { const uint32_t i = top_first + (uint32_t)__builtin_ctz(rem | 0x100u); const float4* rp = nodes + NS * i; nx_a = rp[0]; nx_b = rp[1]; }
+      { const uint32_t c = (uint32_t)__builtin_ctz(rem | 0x100u); nx_a = rec(blk + NS * c); nx_b = rec(blk + NS * c + 1); }
       if (COUNT) { if (uni(__float_as_uint(nb.w)) != 0u) tl.w[1]++; if ((mine_m >> lane) & 1ull) tl.node++; }
       if (!any_zero) {
         bool c_acc, c_rej;
@@ -184,8 +192,9 @@ __device__ __forceinline__ void trace_wave(const float4* __restrict__ nodes, int
           sp++;
         }
         top_first = first; rem = crem; top_mask = acc_m; mine_m = acc_m;
-        const uint32_t i = top_first + (uint32_t)__builtin_ctz(rem);
-        nx_a = nodes[NS * i]; nx_b = nodes[NS * i + 1];
+        blk = cnodes + NS * top_first;
+        const uint32_t c = (uint32_t)__builtin_ctz(rem);
+        nx_a = rec(blk + NS * c); nx_b = rec(blk + NS * c + 1);
         continue;
       }
       const int32_t count = (int32_t)meta;
