@@ -118,18 +118,33 @@ __device__ __forceinline__ void trace_wave(const float4* __restrict__ nodes, int
       if (presorted) {
         // Siblings are scanned in a tight loop until one is accepted by some lane (or needs the exact test): about two
         // node tests in three end in "no lane", and those never leave this loop.
+        // A record is consumed by six subtractions (plane - e) and two scalar copies (links); the request for the next
+        // sibling is tied to those results, so it is issued afterwards and its data may land in the very registers the
+        // record occupied: nothing is copied from "next" to "current".  Whoever needs the planes again (the exact test,
+        // rarely) reads the record once more.
+        uint32_t c_cur = 0u, r_first = 0u, r_meta = 0u;
         for (;;) {
+          c_cur = (uint32_t)__builtin_ctz(rem);
           rem &= rem - 1u;
-          na = nx_a; nb = nx_b;
-          // next sibling ("child 8" after the last one is the first record of the next block or the pad record)
-          { const uint32_t c = (uint32_t)__builtin_ctz(rem | 0x100u); nx_a = rec(blk + NS * c); nx_b = rec(blk + NS * c + 1); }
-          if (COUNT) { if (uni(__float_as_uint(nb.w)) != 0u) tl.w[1]++; if ((mine_m >> lane) & 1ull) tl.node++; }   // w[1]: iterations the plain variant also makes
+          const float dx0 = nx_a.x - e.x, dx1 = nx_a.y - e.x, dy0 = nx_a.z - e.y, dy1 = nx_a.w - e.y, dz0 = nx_b.x - e.z, dz1 = nx_b.y - e.z;
+          r_first = uni(__float_as_uint(nx_b.z)); r_meta = uni(__float_as_uint(nx_b.w));
+          {
+            // next sibling ("child 8" after the last one is the first record of the next block or the pad record)
+            uint32_t off = (uint32_t)__builtin_ctz(rem | 0x100u) * 32u;   // byte offset of that record within the block
+            asm volatile("" : "+s"(off) : "v"(dx0), "v"(dx1), "v"(dy0), "v"(dy1), "v"(dz0), "v"(dz1), "s"(r_first), "s"(r_meta));
+            const cnode_ptr rp = (cnode_ptr)((const __attribute__((address_space(4))) char*)blk + off);
+            nx_a = rec(rp); nx_b = rec(rp + 1);
+          }
+          if (COUNT) { if (r_meta != 0u) tl.w[1]++; if ((mine_m >> lane) & 1ull) tl.node++; }   // w[1]: iterations the plain variant also makes
           bool c_acc, c_rej;
-          rt_node_slab_presorted(na.x, na.y, na.z, na.w, nb.x, nb.y, e, inv, hit.t, c_acc, c_rej);
+          rt_node_slab_sorted(dx0 * inv.x, dx1 * inv.x, dy0 * inv.y, dy1 * inv.y, dz0 * inv.z, dz1 * inv.z, hit.t, c_acc, c_rej);
           acc_m = __builtin_amdgcn_ballot_w64(c_acc) & mine_m;
           und_m = mine_m & ~(acc_m | __builtin_amdgcn_ballot_w64(c_rej));
           if ((acc_m | und_m) != 0ull || rem == 0u) break;
         }
+        if (und_m) { na = rec(blk + NS * c_cur); nb = rec(blk + NS * c_cur + 1); }
+        else { na = float4{0.f, 0.f, 0.f, 0.f}; nb = float4{0.f, 0.f, __uint_as_float(r_first), __uint_as_float(r_meta)}; }
+        nb.z = __uint_as_float(r_first); nb.w = __uint_as_float(r_meta);
       } else {
       rem &= rem - 1u;
       na = nx_a; nb = nx_b;
