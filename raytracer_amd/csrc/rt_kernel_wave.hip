@@ -39,6 +39,14 @@ __device__ __forceinline__ uint64_t uni64(uint64_t v) {
 //   want   : this lane has a ray to trace
 //   stop_t : >= 0 for a shadow ray: the lane drops out as soon as its t falls below stop_t, because
 //            only "t < light distance" is consumed (ray.cu:70) and t never grows; < 0 = never
+// Wave-level path counters (how often each part of the walk runs) are kept by the instrumented variant, and by the
+// plain one too in a build with -DRT_PATH_COUNTS (measurements; off in the product).
+#ifdef RT_PATH_COUNTS
+#define RT_PATHS_ON true
+#else
+#define RT_PATHS_ON false
+#endif
+
 template <bool COUNT>
 __device__ __forceinline__ void trace_wave(const float4* __restrict__ nodes, int n_wnodes, const float4* __restrict__ tri_leaf,
                                            const RtSphere* __restrict__ spheres, int n_spheres, bool has_oct, bool want,
@@ -47,9 +55,10 @@ __device__ __forceinline__ void trace_wave(const float4* __restrict__ nodes, int
   // Lane sets are kept as wave-uniform 64-bit masks in SGPRs (who still has an undecided ray, who entered the
   // current branch, who accepted the current node, ...); they are combined on the scalar unit and only turned
   // back into a per-lane predicate on the rare paths that need one.
+  constexpr bool PATHS = COUNT || RT_PATHS_ON;
   uint64_t live = __builtin_amdgcn_ballot_w64(want);
   if (!live) return;
-  if (COUNT) tl.w[0]++;
+  if (PATHS) tl.w[0]++;
   const RtVec3 inv = {1.f / d.x, 1.f / d.y, 1.f / d.z};   // only feeds the conservative classification
   const RtVec3 c2 = {-d.x, -d.y, -d.z};                   // third column of the triangle solve (triangle.cu:118-120)
   const v2f e_xy = {e.x, e.y}, c_zx = {c2.z, c2.x}, c_yz = {c2.y, c2.z}, c_yx = {c2.y, c2.x};
@@ -135,7 +144,8 @@ __device__ __forceinline__ void trace_wave(const float4* __restrict__ nodes, int
             const cnode_ptr rp = (cnode_ptr)((const __attribute__((address_space(4))) char*)blk + off);
             nx_a = rec(rp); nx_b = rec(rp + 1);
           }
-          if (COUNT) { if (r_meta != 0u) tl.w[1]++; if ((mine_m >> lane) & 1ull) tl.node++; }   // w[1]: iterations the plain variant also makes
+          if (PATHS && r_meta != 0u) tl.w[1]++;
+          if (COUNT && ((mine_m >> lane) & 1ull)) tl.node++;   // w[1]: iterations the plain variant also makes
           bool c_acc, c_rej;
           rt_node_slab_sorted(dx0 * inv.x, dx1 * inv.x, dy0 * inv.y, dy1 * inv.y, dz0 * inv.z, dz1 * inv.z, hit.t, c_acc, c_rej);
           acc_m = __builtin_amdgcn_ballot_w64(c_acc) & mine_m;
@@ -149,7 +159,8 @@ __device__ __forceinline__ void trace_wave(const float4* __restrict__ nodes, int
       rem &= rem - 1u;
       na = nx_a; nb = nx_b;
       { const uint32_t c = (uint32_t)__builtin_ctz(rem | 0x100u); nx_a = rec(blk + NS * c); nx_b = rec(blk + NS * c + 1); }
-      if (COUNT) { if (uni(__float_as_uint(nb.w)) != 0u) tl.w[1]++; if ((mine_m >> lane) & 1ull) tl.node++; }
+      if (PATHS && uni(__float_as_uint(nb.w)) != 0u) tl.w[1]++;
+      if (COUNT && ((mine_m >> lane) & 1ull)) tl.node++;
       if (!any_zero) {
         bool c_acc, c_rej;
         rt_node_slab_fast(na.x, na.y, na.z, na.w, nb.x, nb.y, e, inv, hit.t, c_acc, c_rej);
@@ -175,7 +186,7 @@ __device__ __forceinline__ void trace_wave(const float4* __restrict__ nodes, int
       }
       }
       if (und_m) {
-        if (COUNT) tl.w[2]++;
+        if (PATHS) tl.w[2]++;
         // Rare path (about 1 % of the node tests): the per-ray constants of the exact test are derived here, from
         // values the compiler cannot hoist, instead of occupying registers across the whole walk.
         RtVec3 dd = d, ee = e; float T = hit.t;
@@ -188,7 +199,7 @@ __device__ __forceinline__ void trace_wave(const float4* __restrict__ nodes, int
         uint64_t pos_m = __builtin_amdgcn_ballot_w64(S > 0.f);
         const uint64_t tie_m = __builtin_amdgcn_ballot_w64(S == 0.f) & und_m;
         if (tie_m) {   // a boundary case: settle it with the compare form
-          if (COUNT) tl.w[3]++;
+          if (PATHS) tl.w[3]++;
           const bool ex = rt_node_accept_exact(ini, end, ee, dd, rc, rt_t_const(rc, T));
           pos_m = (pos_m & ~tie_m) | (__builtin_amdgcn_ballot_w64(ex) & tie_m);
         }
@@ -219,7 +230,7 @@ __device__ __forceinline__ void trace_wave(const float4* __restrict__ nodes, int
       uint64_t changed_m = 0ull;
       // One triangle: the record is in SGPRs (q0..q3 as laid out in RtTriLeaf), every lane of acc_m tests it.
       auto test_triangle = [&](const float4& q0, const float4& q1, const float4& q2, const float4& q3) {
-        if (COUNT) tl.w[4]++;
+        if (PATHS) tl.w[4]++;
         // stage 1: determinant and beta numerator (triangle.cu:117-131, first column of cofactors); the operations and
         // their order are the reference's, paired two to an instruction
         const v2f bxy = e_xy - v2f{q0.x, q0.y};
@@ -241,7 +252,7 @@ __device__ __forceinline__ void trace_wave(const float4* __restrict__ nodes, int
         // 0 <= beta <= 1  <=>  0 <= nbs <= |det|   (det == 0 cannot survive stage 3: 0 < nts <= 0)
         uint64_t pass_m = __builtin_amdgcn_ballot_w64(nbs >= 0.f) & __builtin_amdgcn_ballot_w64(nbs <= ad) & acc_m;
         if (!pass_m) return;
-        if (COUNT) tl.w[5]++;
+        if (PATHS) tl.w[5]++;
         const RtVec3 e1 = {q1.x, q1.y, q1.z}, e2 = {q2.x, q2.y, q2.w};
         const RtVec3 b = {bxy.x, bxy.y, bz};
         // stage 2: gamma numerator
@@ -252,7 +263,7 @@ __device__ __forceinline__ void trace_wave(const float4* __restrict__ nodes, int
         const float ngs = rt_from_bits(rt_bits(n.ng) ^ s);
         pass_m &= __builtin_amdgcn_ballot_w64(ngs >= 0.f) & __builtin_amdgcn_ballot_w64(ngs <= ad);
         if (!pass_m) return;
-        if (COUNT) tl.w[6]++;
+        if (PATHS) tl.w[6]++;
         // stage 3: t numerator; t > 0, and t clearly beyond the closest hit is rejected without dividing
         const float m02 = e1.y * e2.z - e1.z * e2.y;
         const float m12 = -e1.x * e2.z + e1.z * e2.x;
@@ -261,7 +272,7 @@ __device__ __forceinline__ void trace_wave(const float4* __restrict__ nodes, int
         const float nts = rt_from_bits(rt_bits(n.nt) ^ s);
         pass_m &= __builtin_amdgcn_ballot_w64(nts > 0.f) & __builtin_amdgcn_ballot_w64(nts <= (hit.t * ad) * 1.000001f);
         if (!pass_m) return;
-        if (COUNT) tl.w[7]++;
+        if (PATHS) tl.w[7]++;
         if ((pass_m >> lane) & 1ull) {   // the reference's quotients decide (triangle.cu:131-137)
           float t, bet, gam;
           if (rt_triangle_finish(n, hit.t, t, bet, gam)) { hit.t = t; hit.prim = (int32_t)__float_as_uint(q0.w); hit.bet = bet; hit.gam = gam; }
@@ -637,7 +648,7 @@ __global__ __launch_bounds__(RT_BLOCK, BOUNCE ? RT_WAVES_PER_SIMD_BOUNCE : RT_WA
     for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
     if (lane == 0 && v) atomicAdd(&counters[slot[k]], (unsigned long long)v);
   }
-  if (COUNT && lane == 0) for (int k = 0; k < 8; k++) if (tl.w[k]) atomicAdd(&counters[C_W_TRACE + k], (unsigned long long)tl.w[k]);
+  if ((COUNT || RT_PATHS_ON) && lane == 0) for (int k = 0; k < 8; k++) if (tl.w[k]) atomicAdd(&counters[C_W_TRACE + k], (unsigned long long)tl.w[k]);
 }
 
 }  // namespace
