@@ -72,7 +72,12 @@ typedef struct rt_stats {
 enum {
   RT_RENDER_COUNT_TESTS = 1,  /* run the instrumented variant that counts node / leaf / triangle / sphere tests */
   RT_RENDER_TIME = 2,         /* bracket the kernels with HIP events on `stream` and synchronise */
-  RT_RENDER_LITERAL = 4       /* cross-check kernel: one private stack per pixel, the reference's solves evaluated as written */
+  RT_RENDER_LITERAL = 4,      /* cross-check kernel: one private stack per pixel, the reference's solves evaluated as written */
+  /* Bounce rays are either kept on each pixel's own 10-entry stack inside one kernel launch (ray/ray.cuh:10-33), or
+   * appended to queues and rendered generation by generation, 64 per wave, their contributions summed per pixel in the
+   * stack's order afterwards.  Same bytes either way; the library picks (queues for glass meshes).  These force one. */
+  RT_RENDER_STACKED = 8,
+  RT_RENDER_QUEUED = 16
 };
 
 /* Parse resources + scene, load and transform meshes, build the octree.

@@ -22,6 +22,8 @@ LIB_PATH = os.environ.get("RT_AMD_LIB") or os.path.join(_HERE, "librt_amd.so")
 RT_RENDER_COUNT_TESTS = 1
 RT_RENDER_TIME = 2
 RT_RENDER_LITERAL = 4
+RT_RENDER_STACKED = 8
+RT_RENDER_QUEUED = 16
 
 # Every symbol include/rt_amd.h declares.
 ABI_SYMBOLS = (

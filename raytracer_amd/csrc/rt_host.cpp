@@ -754,6 +754,24 @@ void load_scene_into(rt_scene& sc, const std::string& scene_path, const std::str
   I.n_nodes = sc.nodes.empty() ? 0 : (int32_t)sc.nodes.size() - 1; I.shadows_enabled = c.shadows;
   if (!sc.nodes.empty()) tree_summary(sc, 0, 0, I);
   for (int32_t mi : sc.mat_index) if (sc.materials[mi].type == RT_REFLECTIVE || sc.materials[mi].type == RT_DIELECTRIC) I.has_bounce_materials = 1;
+  {
+    auto pushes_of = [&](int32_t first, int32_t count) {
+      int32_t p = 0;
+      for (int32_t k = 0; k < count; k++) {
+        const int32_t t = sc.materials[sc.mat_index[first + k]].type;
+        p += t == RT_REFLECTIVE ? 1 : (t == RT_DIELECTRIC ? 2 : 0);
+      }
+      return p;
+    };
+    sc.max_pushes_per_hit = 0;
+    for (const RtSphere& sp : sc.spheres) sc.max_pushes_per_hit = std::max(sc.max_pushes_per_hit, pushes_of(sp.mat_first, sp.mat_count));
+    sc.dielectric_mesh = 0;
+    for (size_t m = 0; m < sc.mesh_mat_first.size(); m++) {
+      sc.max_pushes_per_hit = std::max(sc.max_pushes_per_hit, pushes_of(sc.mesh_mat_first[m], sc.mesh_mat_count[m]));
+      for (int32_t k = 0; k < sc.mesh_mat_count[m]; k++)
+        if (sc.materials[sc.mat_index[sc.mesh_mat_first[m] + k]].type == RT_DIELECTRIC) sc.dielectric_mesh = 1;
+    }
+  }
 }
 
 void dump_tree_rec(const rt_scene& sc, int32_t id, int32_t* kind, float* bounds, int32_t* refs, size_t& ni, size_t& ri) {

@@ -93,6 +93,8 @@ struct rt_scene {
   std::vector<RtTriShade> tri_shade;
   std::vector<float> tri_verts, tri_normals;      // n*9 each, as the reference uploads them
   rt_scene_info info;
+  int32_t max_pushes_per_hit = 0;                 // most rays one hit can push: 1 per reflective, 2 per dielectric material of a primitive
+  int32_t dielectric_mesh = 0;                    // some mesh carries a dielectric material
 };
 
 void rt_set_error(const std::string& msg);

@@ -376,7 +376,8 @@ __global__ __launch_bounds__(RT_BLOCK, BOUNCE ? RT_WAVES_PER_SIMD_BOUNCE : RT_WA
     const float4* __restrict__ tri_geom, const float4* __restrict__ tri_shade, const RtSphere* __restrict__ spheres,
     const RtLight* __restrict__ lights, const RtMaterial* __restrict__ materials, const int32_t* __restrict__ mat_index,
     const int32_t* __restrict__ mesh_mat_first, const int32_t* __restrict__ mesh_mat_count, int n_spheres, int n_lights, int has_oct, int n_wnodes,
-    uint8_t* __restrict__ rgb, int32_t* __restrict__ ids, float* __restrict__ ts, unsigned long long* __restrict__ counters_all, int tally) {
+    uint8_t* __restrict__ rgb, int32_t* __restrict__ ids, float* __restrict__ ts, unsigned long long* __restrict__ counters_all, int tally,
+    const RtQueues wf) {
   unsigned long long* const counters = counters_all + ((blockIdx.x + blockIdx.y) & (RT_COUNTER_COPIES - 1)) * RT_COUNTER_STRIDE;
   __shared__ float parked[ShadeState<BOUNCE>::WORDS * RT_BLOCK];
   __shared__ uint32_t pack[RT_BLOCK / 64][48];
@@ -415,7 +416,9 @@ __global__ __launch_bounds__(RT_BLOCK, BOUNCE ? RT_WAVES_PER_SIMD_BOUNCE : RT_WA
   RtVec3 tr_e, tr_d;        // ray being traced
   float tr_stop = -1.f;     // >= 0: shadow ray, length to the light
   int phase;
-  {
+  const bool wavefront = BOUNCE && wf.enabled != 0;        // bounce rays leave through the queue
+  const bool queued = BOUNCE && wf.in != nullptr;           // this launch renders a queue of bounce rays, one per lane
+  if (!queued) {
     const Pixel px0 = pixel_of(tid);
     phase = px0.valid ? PH_CLOSEST : PH_DONE;
     const int i = px0.col, j = H - 1 - px0.row;   // camera.cu:94,118: j counts from the bottom
@@ -427,7 +430,7 @@ __global__ __launch_bounds__(RT_BLOCK, BOUNCE ? RT_WAVES_PER_SIMD_BOUNCE : RT_WA
     tr_d = rt_normalized(d0);
     tr_e = {c.pos[0], c.pos[1], c.pos[2]};
   }
-  bool primary = true;
+  bool primary = !queued;
   int verdict = -1;   // result of the last shadow ray, until consumed
 
   // ---- shading state (parked during traversal) and the pixel's ray stack (scratch, BOUNCE only) --------
@@ -438,6 +441,51 @@ __global__ __launch_bounds__(RT_BLOCK, BOUNCE ? RT_WAVES_PER_SIMD_BOUNCE : RT_WA
   sh.att = {1.f, 1.f, 1.f}; sh.level0 = c.scene_refr; sh.nlevel = 0; sh.depth = 0;
   BounceRay rstack[BOUNCE ? RT_RAY_STACK : 1];
   int rsp = 0;
+  // queue mode: where the lane's ray sits in its pixel's ray tree, how many rays it has pushed, whether the pixel is
+  // finished by the term list instead of by this lane
+  uint32_t q_pixel = 0u; unsigned long long q_path = 0ull; int q_pushes = 0; bool q_pending = false;
+  if (queued) {
+    const uint32_t gid = blockIdx.x * RT_BLOCK + tid;
+    phase = PH_DONE; tr_e = {0.f, 0.f, 0.f}; tr_d = {0.f, 0.f, 1.f};
+    if (gid < wf.n_in) {
+      const RtQRay& q = wf.in[gid];
+      tr_e = ld3(q.e); tr_d = ld3(q.d); sh.att = ld3(q.att);
+      sh.level0 = q.level[0]; sh.level1 = q.level[1]; sh.level2 = q.level[2]; sh.nlevel = q.nlevel; sh.depth = q.depth;
+      q_pixel = q.pixel; q_path = q.path;
+      phase = PH_CLOSEST; tl.rays++;
+    }
+    sh.view = tr_d;
+  }
+  // A ray pushed by the hit being shaded (ray.cuh:22-27): onto the lane's stack, or into the queue of the next generation.
+  auto push_ray = [&](const RtVec3& eye, const RtVec3& dir, const RtVec3& att, int nlevel) {
+    if (BOUNCE && wavefront) {
+      if (!queued && q_pushes == 0) { const Pixel px = pixel_of(tid); q_pixel = (uint32_t)((size_t)px.orow * W + px.col); }
+      // one slot per pushing lane: the lanes active here count themselves and the first of them reserves the run
+      const uint64_t m = __builtin_amdgcn_ballot_w64(true);
+      const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+      uint32_t base = 0u;
+      if (rank == 0u) base = atomicAdd(wf.out_count, (uint32_t)__builtin_popcountll(m));
+      base = __builtin_amdgcn_readfirstlane(base);
+      const uint32_t slot = base + rank;
+      const int depth = sh.depth + 1;
+      if (slot < wf.out_cap) {   // (an overflow shows in the count; the host then renders the frame the other way)
+        RtQRay& q = wf.out[slot];
+        q.e[0] = eye.x; q.e[1] = eye.y; q.e[2] = eye.z; q.d[0] = dir.x; q.d[1] = dir.y; q.d[2] = dir.z;
+        q.att[0] = att.x; q.att[1] = att.y; q.att[2] = att.z;
+        q.level[0] = sh.level0; q.level[1] = sh.level1; q.level[2] = sh.level2; q.nlevel = nlevel; q.depth = depth;
+        q.pixel = q_pixel; q.pad = 0u;
+        q.path = q_path | ((unsigned long long)(RT_PATH_MAX_PUSHES - q_pushes) << (RT_PATH_BITS - 4 * depth));
+      }
+      q_pushes++;
+    } else if (BOUNCE) {
+      if (rsp < RT_RAY_STACK) {
+        BounceRay& r = rstack[rsp++];
+        r.eye = eye; r.dir = dir; r.att = att;
+        r.level[0] = sh.level0; r.level[1] = sh.level1; r.level[2] = sh.level2;
+        r.nlevel = nlevel; r.depth = sh.depth + 1;
+      } else atomicAdd(&counters[C_UB_STACK], 1ull);
+    }
+  };
 
   while (__builtin_amdgcn_ballot_w64(phase != PH_DONE)) {
     // ---- trace the pending rays of the wave ---------------------------------------------------------
@@ -483,6 +531,23 @@ __global__ __launch_bounds__(RT_BLOCK, BOUNCE ? RT_WAVES_PER_SIMD_BOUNCE : RT_WA
       phase = PH_SHADE;
       while (phase == PH_SHADE) {
         if (sh.mi >= sh.mcount) {   // every material of the hit handled: camera.cu:110-111, then next ray of the pixel
+          if (BOUNCE && wavefront && (queued || q_pushes > 0)) {
+            // the ray's contribution goes to the term list; the pixel is summed up from there, in the reference's order
+            if (!queued && q_pushes == 0) { const Pixel px = pixel_of(tid); q_pixel = (uint32_t)((size_t)px.orow * W + px.col); }
+            const uint64_t m = __builtin_amdgcn_ballot_w64(true);
+            const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+            uint32_t base = 0u;
+            if (rank == 0u) base = atomicAdd(wf.term_count, (uint32_t)__builtin_popcountll(m));
+            base = __builtin_amdgcn_readfirstlane(base);
+            const uint32_t slot = base + rank;
+            if (slot < wf.term_cap) {
+              wf.term_keys[slot] = ((unsigned long long)q_pixel << RT_PATH_BITS) | q_path;
+              wf.term_vals[slot] = RtTermRGB{sh.att.x * sh.colr.x, sh.att.y * sh.colr.y, sh.att.z * sh.colr.z, 0.f};
+            }
+            q_pending = true;
+            phase = PH_DONE;
+            break;
+          }
           sh.color.x = sh.color.x + sh.att.x * sh.colr.x;
           sh.color.y = sh.color.y + sh.att.y * sh.colr.y;
           sh.color.z = sh.color.z + sh.att.z * sh.colr.z;
@@ -547,13 +612,8 @@ __global__ __launch_bounds__(RT_BLOCK, BOUNCE ? RT_WAVES_PER_SIMD_BOUNCE : RT_WA
             const float s2 = 2 * rt_dot(vd, N);
             const RtVec3 rl = rt_normalized({vd.x - N.x * s2, vd.y - N.y * s2, vd.z - N.z * s2});
             if (M.type == RT_REFLECTIVE) {   // material.cu:25-35
-              if (rsp < RT_RAY_STACK) {
-                BounceRay& r = rstack[rsp++];
-                r.eye = {P.x + rl.x * RT_EPS, P.y + rl.y * RT_EPS, P.z + rl.z * RT_EPS}; r.dir = rl;
-                r.att = {M.col[0] * sh.att.x, M.col[1] * sh.att.y, M.col[2] * sh.att.z};
-                r.level[0] = sh.level0; r.level[1] = sh.level1; r.level[2] = sh.level2;
-                r.nlevel = sh.nlevel; r.depth = sh.depth + 1;
-              } else atomicAdd(&counters[C_UB_STACK], 1ull);
+              push_ray({P.x + rl.x * RT_EPS, P.y + rl.y * RT_EPS, P.z + rl.z * RT_EPS}, rl,
+                       {M.col[0] * sh.att.x, M.col[1] * sh.att.y, M.col[2] * sh.att.z}, sh.nlevel);
             } else {   // RT_DIELECTRIC, material.cu:36-99
               const float refr = sh.level_at(sh.nlevel);
               const RtVec3 rlsP = {P.x + N.x * RT_EPS, P.y + N.y * RT_EPS, P.z + N.z * RT_EPS};
@@ -584,21 +644,10 @@ __global__ __launch_bounds__(RT_BLOCK, BOUNCE ? RT_WAVES_PER_SIMD_BOUNCE : RT_WA
                   nl = sh.nlevel - 1;
                   if (nl < 0) { nl = 0; atomicAdd(&counters[C_UB_LEAVE], 1ull); }
                 }
-                if (rsp < RT_RAY_STACK) {
-                  BounceRay& r = rstack[rsp++];
-                  r.eye = {P.x + rf.x * RT_EPS, P.y + rf.y * RT_EPS, P.z + rf.z * RT_EPS}; r.dir = rf;
-                  r.att = {attf[0], attf[1], attf[2]};
-                  r.level[0] = sh.level0; r.level[1] = sh.level1; r.level[2] = sh.level2;
-                  r.nlevel = nl; r.depth = sh.depth + 1;
-                } else atomicAdd(&counters[C_UB_STACK], 1ull);
+                push_ray({P.x + rf.x * RT_EPS, P.y + rf.y * RT_EPS, P.z + rf.z * RT_EPS}, rf, {attf[0], attf[1], attf[2]}, nl);
                 for (int k = 0; k < 3; k++) attl[k] = attl[k] * fresnel;
               }
-              if (rsp < RT_RAY_STACK) {
-                BounceRay& r = rstack[rsp++];
-                r.eye = rlsP; r.dir = rl; r.att = {attl[0], attl[1], attl[2]};
-                r.level[0] = sh.level0; r.level[1] = sh.level1; r.level[2] = sh.level2;
-                r.nlevel = sh.nlevel; r.depth = sh.depth + 1;
-              } else atomicAdd(&counters[C_UB_STACK], 1ull);
+              push_ray(rlsP, rl, {attl[0], attl[1], attl[2]}, sh.nlevel);
             }
           }
           sh.mi++; sh.li = 0;
@@ -610,33 +659,32 @@ __global__ __launch_bounds__(RT_BLOCK, BOUNCE ? RT_WAVES_PER_SIMD_BOUNCE : RT_WA
   // ---- quantise (camera.cu:113-122; NaN < 1 is false, so NaN -> 1 -> 255) and store -------------------------
   // A tile row is 24 contiguous bytes.  The wave packs its 192 bytes through LDS and stores them as 48 aligned
   // dwords instead of 192 single bytes (each byte store is its own partial write to memory).
-  uint8_t q[3];
-  for (int k = 0; k < 3; k++) {
-    const float ck = k == 0 ? sh.color.x : (k == 1 ? sh.color.y : sh.color.z);
-    const float v = (ck < 1.f ? ck : 1.f) * 255.f;
-    q[k] = v < 0.f ? (uint8_t)0 : (uint8_t)(int)v;
-  }
-  const Pixel pxe = pixel_of(tid);
-  int wave = tid; asm volatile("" : "+v"(wave)); wave >>= 6;
-  if (pxe.valid) tl.rays++;   // the primary ray
-  const int col0 = pxe.col & ~7, lrow0 = pxe.lrow & ~7;   // tile origin (wave-uniform)
-  const int last_row = rows.row0 + ((lrow0 + 7) / rows.band_rows) * rows.band_stride + (lrow0 + 7) % rows.band_rows;
-  const bool whole = !rows.small && (W & 3) == 0 && col0 + 8 <= W && lrow0 + 8 <= rows.n_local && last_row < H &&
-                     (lrow0 / rows.band_rows) == ((lrow0 + 7) / rows.band_rows);   // wave-uniform
-  if (whole) {
-    uint8_t* pk = (uint8_t*)pack[wave];
-    pk[lane * 3 + 0] = q[0]; pk[lane * 3 + 1] = q[1]; pk[lane * 3 + 2] = q[2];
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    if (lane < 48) {
-      const int r = lane / 6, j = lane - 6 * r;
-      const int orow0 = rows.compact ? lrow0 : (rows.row0 + (lrow0 / rows.band_rows) * rows.band_stride + lrow0 % rows.band_rows);
-      uint32_t* dst = (uint32_t*)(rgb + ((size_t)(orow0 + r) * W + col0) * 3) + j;
-      *dst = pack[wave][r * 6 + j];
+  // (Pixels whose rays went through the queues are written again, with their sum, by the resolve kernel.)
+  if (!queued) {
+    const uint8_t q[3] = {rt_quantise(sh.color.x), rt_quantise(sh.color.y), rt_quantise(sh.color.z)};
+    const Pixel pxe = pixel_of(tid);
+    int wave = tid; asm volatile("" : "+v"(wave)); wave >>= 6;
+    if (pxe.valid) tl.rays++;   // the primary ray
+    const int col0 = pxe.col & ~7, lrow0 = pxe.lrow & ~7;   // tile origin (wave-uniform)
+    const int last_row = rows.row0 + ((lrow0 + 7) / rows.band_rows) * rows.band_stride + (lrow0 + 7) % rows.band_rows;
+    const bool whole = !rows.small && (W & 3) == 0 && col0 + 8 <= W && lrow0 + 8 <= rows.n_local && last_row < H &&
+                       (lrow0 / rows.band_rows) == ((lrow0 + 7) / rows.band_rows);   // wave-uniform
+    if (whole) {
+      uint8_t* pk = (uint8_t*)pack[wave];
+      pk[lane * 3 + 0] = q[0]; pk[lane * 3 + 1] = q[1]; pk[lane * 3 + 2] = q[2];
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      if (lane < 48) {
+        const int r = lane / 6, j = lane - 6 * r;
+        const int orow0 = rows.compact ? lrow0 : (rows.row0 + (lrow0 / rows.band_rows) * rows.band_stride + lrow0 % rows.band_rows);
+        uint32_t* dst = (uint32_t*)(rgb + ((size_t)(orow0 + r) * W + col0) * 3) + j;
+        *dst = pack[wave][r * 6 + j];
+      }
+    } else if (pxe.valid) {
+      const size_t p = ((size_t)pxe.orow * W + pxe.col) * 3;
+      rgb[p] = q[0]; rgb[p + 1] = q[1]; rgb[p + 2] = q[2];
     }
-  } else if (pxe.valid) {
-    const size_t p = ((size_t)pxe.orow * W + pxe.col) * 3;
-    rgb[p] = q[0]; rgb[p + 1] = q[1]; rgb[p + 2] = q[2];
   }
+  (void)q_pending;
 
   // work counters: wave reduction, one atomic per wave and counter
   if (!tally) return;   // nobody asked for statistics
@@ -654,16 +702,41 @@ __global__ __launch_bounds__(RT_BLOCK, BOUNCE ? RT_WAVES_PER_SIMD_BOUNCE : RT_WA
 }  // namespace
 
 void rt_launch_wave_kernel(const RtDeviceView& V, const RowMap& rows, bool bounce, bool count, uint8_t* rgb, int32_t* ids,
-                           float* ts, unsigned long long* counters, bool tally, hipStream_t stream) {
+                           float* ts, unsigned long long* counters, bool tally, const RtQueues& wf, hipStream_t stream) {
   const int tw = rows.small ? RT_TILE_W / 2 : RT_TILE_W, th = rows.small ? RT_TILE_H / 2 : RT_TILE_H;
-  const dim3 grid((V.cam.width + tw - 1) / tw, (rows.n_local + th - 1) / th), block(RT_BLOCK);
+  dim3 grid((V.cam.width + tw - 1) / tw, (rows.n_local + th - 1) / th), block(RT_BLOCK);
+  if (wf.in) { grid = dim3((wf.n_in + RT_BLOCK - 1) / RT_BLOCK, 1); bounce = true; }   // one queued ray per lane
 #define LAUNCH(B, C)                                                                                                             \
   hipLaunchKernelGGL((render_wave<B, C>), grid, block, 0, stream, V.cam, rows, V.wnodes, V.tri_leaf, V.tri_geom, V.tri_shade,     \
                      V.spheres, V.lights, V.materials, V.mat_index, V.mesh_mat_first, V.mesh_mat_count, V.n_spheres, V.n_lights, \
-                     V.has_oct, V.n_wnodes, rgb, ids, ts, counters, tally ? 1 : 0)
+                     V.has_oct, V.n_wnodes, rgb, ids, ts, counters, tally ? 1 : 0, wf)
   if (bounce && count) LAUNCH(true, true);
   else if (bounce) LAUNCH(true, false);
   else if (count) LAUNCH(false, true);
   else LAUNCH(false, false);
 #undef LAUNCH
+}
+
+namespace {
+// One thread per term; the thread that holds the first term of a pixel adds up that pixel's terms in key order
+// (camera.cu:110-111: colour = colour + att * ray colour, starting from 0) and stores the pixel.
+__global__ __launch_bounds__(256) void resolve_terms(const unsigned long long* __restrict__ keys, const RtTermRGB* __restrict__ vals,
+                                                     uint32_t n, uint8_t* __restrict__ rgb) {
+  const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+  if (i >= n) return;
+  const unsigned long long pixel = keys[i] >> RT_PATH_BITS;
+  if (i > 0u && (keys[i - 1] >> RT_PATH_BITS) == pixel) return;
+  float r = 0.f, g = 0.f, b = 0.f;
+  for (uint32_t j = i; j < n && (keys[j] >> RT_PATH_BITS) == pixel; j++) {
+    const RtTermRGB t = vals[j];
+    r = r + t.r; g = g + t.g; b = b + t.b;
+  }
+  uint8_t* dst = rgb + (size_t)pixel * 3;
+  dst[0] = rt_quantise(r); dst[1] = rt_quantise(g); dst[2] = rt_quantise(b);
+}
+}  // namespace
+
+void rt_launch_resolve_terms(const unsigned long long* keys, const RtTermRGB* vals, uint32_t n, uint8_t* rgb, hipStream_t stream) {
+  if (n == 0) return;
+  hipLaunchKernelGGL(resolve_terms, dim3((n + 255u) / 256u), dim3(256), 0, stream, keys, vals, n, rgb);
 }

@@ -60,6 +60,39 @@ struct BounceRay {   // the fields of DRay that survive a push (vector.cu:188-20
   int32_t nlevel, depth;
 };
 
+// ---- bounce rays handled generation by generation ("wavefront") ---------------------------------------------------
+// A pixel's rays form a tree (a reflective hit pushes one ray, a dielectric hit up to two; ray/ray.cuh:10-33,
+// material.cu:25-99).  The reference works it off a 10-entry LIFO stack per pixel and adds att * colour of every ray to
+// the pixel in the order the rays are processed.  Instead of keeping that stack inside one lane (whose wave then spends
+// dozens of dependent walks on a few pixels while the chip runs empty), every pushed ray can be appended to a queue and
+// the queue rendered by the next launch with 64 of them per wave.  What each ray contributes is appended to a term list
+// with a key that sorts the terms of a pixel into the reference's processing order; a last kernel adds them up in that
+// order, so the float sums, and the bytes, are the reference's.
+//   path: 4 bits per tree level, level 1 in bits 35..32; the digit of the k-th push of a ray is 15 - k, so that a ray
+//         pushed later (popped earlier by the LIFO stack) sorts first, a parent (shorter path, zero-padded) before its
+//         children, and a whole subtree before the next sibling: depth-first order, last pushed first = the stack's.
+struct RtQRay {   // 80 B
+  float e[3], d[3], att[3], level[RT_MAX_LEVELS];
+  int32_t nlevel, depth;
+  uint32_t pixel;     // position in the output buffer, in pixels
+  uint32_t pad;
+  unsigned long long path;
+};
+struct RtTermRGB { float r, g, b, pad; };
+#define RT_PATH_BITS 36
+#define RT_PATH_MAX_PUSHES 15   // per ray
+struct RtQueues {
+  const RtQRay* in; RtQRay* out; uint32_t* out_count;                 // in == nullptr: the pass that casts the primary rays
+  unsigned long long* term_keys; RtTermRGB* term_vals; uint32_t* term_count;
+  uint32_t n_in, out_cap, term_cap; int32_t enabled;
+};
+
+// camera.cu:113-122: min(c, 1) * 255 truncated; NaN < 1 is false, so NaN -> 1 -> 255; negatives stored as 0
+__device__ __forceinline__ uint8_t rt_quantise(float c) {
+  const float v = (c < 1.f ? c : 1.f) * 255.f;
+  return v < 0.f ? (uint8_t)0 : (uint8_t)(int)v;
+}
+
 __device__ __forceinline__ RtVec3 ld3(const float* p) { return {p[0], p[1], p[2]}; }
 
 // Hit point and shading normal of the accepted primitive (triangle.cu:141-147, spheres.cu:92-93).
@@ -104,7 +137,13 @@ __device__ __forceinline__ RtVec3 refract_dir(const RtVec3& d, const RtVec3& n, 
 // Launchers (one per kernel family); all asynchronous on `stream`.
 void rt_launch_lane_kernel(const RtDeviceView& view, const RowMap& rows, bool bounce, bool count, uint8_t* rgb, int32_t* ids,
                            float* ts, unsigned long long* counters, bool tally, hipStream_t stream);
+// wf.enabled: bounce rays go to wf.out and terms to the term list instead of the in-kernel stack; wf.in != nullptr: the
+// launch renders the rays of that queue instead of primary rays (rows, rgb, ids, ts unused).
 void rt_launch_wave_kernel(const RtDeviceView& view, const RowMap& rows, bool bounce, bool count, uint8_t* rgb, int32_t* ids,
-                           float* ts, unsigned long long* counters, bool tally, hipStream_t stream);
+                           float* ts, unsigned long long* counters, bool tally, const RtQueues& wf, hipStream_t stream);
+// Adds up the sorted terms of every pixel that has any, in key order, quantises and stores the pixel.
+hipError_t rt_sort_terms(void* temp, size_t* temp_bytes, const unsigned long long* keys_in, unsigned long long* keys_out,
+                         const RtTermRGB* vals_in, RtTermRGB* vals_out, uint32_t n, unsigned end_bit, hipStream_t stream);
+void rt_launch_resolve_terms(const unsigned long long* keys, const RtTermRGB* vals, uint32_t n, uint8_t* rgb, hipStream_t stream);
 
 #endif

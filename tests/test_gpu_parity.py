@@ -43,6 +43,18 @@ def _check_scene(name, w, h, depth=3, base_dir=None):
     assert np.array_equal(rgb2, rgb) and np.array_equal(ids2, ids) and np.array_equal(ts2.view(np.uint32), ts.view(np.uint32))
     assert st2["rays"] == st["rays"] and st2["shadow_rays"] == st["shadow_rays"]
     assert st2["rays_traced"] <= st["rays_traced"] == st["rays"]
+    # bounce rays on each lane's own stack instead of generation by generation from queues: same bytes, same counts
+    # (the library picks one of the two per scene; both are forced here)
+    for way in (rt.RT_RENDER_STACKED, rt.RT_RENDER_QUEUED):
+        rgb4, ids4, ts4, st4 = ds.render_host(flags=way)
+        assert np.array_equal(rgb4, rgb2), "queued and stacked bounce rays differ on %d bytes" % int((rgb4 != rgb2).sum())
+        assert np.array_equal(ids4, ids2)
+        for k in ("rays", "shadow_rays", "rays_traced", "ub_leave_level0", "ub_level_overflow", "ub_stack_overflow"):
+            assert st4[k] == st2[k], (name, k, st4[k], st2[k])
+        rgb5, _, _, st5 = ds.render_host(want_ids=False, flags=way | rt.RT_RENDER_COUNT_TESTS)
+        assert np.array_equal(rgb5, rgb)
+        for k in COUNTER_KEYS:
+            assert st5[k] == st[k], (name, k, st5[k], st[k])
     # cross-check kernel (one stack per pixel, the reference's solves evaluated as written): identical output
     rgb3, ids3, ts3, st3 = ds.render_host(flags=rt.RT_RENDER_LITERAL | rt.RT_RENDER_COUNT_TESTS)
     assert np.array_equal(rgb3, rgb) and np.array_equal(ids3, ids) and np.array_equal(ts3.view(np.uint32), ts.view(np.uint32))
