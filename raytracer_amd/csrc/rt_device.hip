@@ -15,6 +15,9 @@ struct WavefrontBuffers {
   RtQRay* queue[2] = {nullptr, nullptr};
   unsigned long long* keys[2] = {nullptr, nullptr};
   RtTermRGB* vals[2] = {nullptr, nullptr};
+  uint32_t* ray_keys[2] = {nullptr, nullptr};   // coherence keys of a queue's rays, unsorted / sorted
+  uint32_t* ray_index[2] = {nullptr, nullptr};  // identity / the sorted order
+  void* ray_sort_temp = nullptr; size_t ray_sort_temp_bytes = 0;
   uint32_t* counts = nullptr;        // [0], [1]: fill of queue[0], queue[1]; [2]: terms
   void* sort_temp = nullptr; size_t sort_temp_bytes = 0;
   uint32_t queue_cap = 0, term_cap = 0;
@@ -61,7 +64,11 @@ extern "C" void rt_dscene_destroy(rt_dscene* d) {
   if (!d) return;
   (void)hipSetDevice(d->device);
   for (void* p : d->allocs) (void)hipFree(p);
-  for (int k = 0; k < 2; k++) { (void)hipFree(d->wf.queue[k]); (void)hipFree(d->wf.keys[k]); (void)hipFree(d->wf.vals[k]); }
+  for (int k = 0; k < 2; k++) {
+    (void)hipFree(d->wf.queue[k]); (void)hipFree(d->wf.keys[k]); (void)hipFree(d->wf.vals[k]);
+    (void)hipFree(d->wf.ray_keys[k]); (void)hipFree(d->wf.ray_index[k]);
+  }
+  (void)hipFree(d->wf.ray_sort_temp);
   (void)hipFree(d->wf.counts); (void)hipFree(d->wf.sort_temp);
   delete d;
 }
@@ -101,7 +108,8 @@ static int render_wavefront(rt_dscene* d, const RowMap& rows, bool count, uint8_
   *done = false;
   const int D = d->view.cam.max_depth, p = d->max_pushes_per_hit;
   const unsigned long long n_out = (unsigned long long)d->view.cam.width * (rows.compact ? rows.n_local : d->view.cam.height);
-  if (p < 1 || p > RT_PATH_MAX_PUSHES || D > 9 || (D - 1) * (p - 1) + p > RT_RAY_STACK || n_out >= (1ull << (64 - RT_PATH_BITS))) return RT_OK;
+  const int path_bits = 4 * std::max(D, 1);
+  if (p < 1 || p > RT_PATH_MAX_PUSHES || D > 9 || (D - 1) * (p - 1) + p > RT_RAY_STACK || n_out >= (1ull << (64 - path_bits))) return RT_OK;
   WavefrontBuffers& B = d->wf;
   const unsigned long long n_px = (unsigned long long)d->view.cam.width * rows.n_local;
   const unsigned long long want_q = std::max<unsigned long long>(1u << 16, 2 * n_px), want_t = std::max<unsigned long long>(1u << 16, 3 * n_px);
@@ -111,6 +119,16 @@ static int render_wavefront(rt_dscene* d, const RowMap& rows, bool count, uint8_
     for (int k = 0; k < 2; k++) { (void)hipFree(B.queue[k]); B.queue[k] = nullptr; }
     B.queue_cap = 0;
     for (int k = 0; k < 2; k++) HIP_TRY(hipMalloc((void**)&B.queue[k], want_q * sizeof(RtQRay)));
+    for (int k = 0; k < 2; k++) {
+      (void)hipFree(B.ray_keys[k]); (void)hipFree(B.ray_index[k]); B.ray_keys[k] = nullptr; B.ray_index[k] = nullptr;
+      HIP_TRY(hipMalloc((void**)&B.ray_keys[k], want_q * sizeof(uint32_t)));
+      HIP_TRY(hipMalloc((void**)&B.ray_index[k], want_q * sizeof(uint32_t)));
+    }
+    (void)hipFree(B.ray_sort_temp); B.ray_sort_temp = nullptr;
+    size_t rb = 0;
+    HIP_TRY(rt_sort_u32(nullptr, &rb, B.ray_keys[0], B.ray_keys[1], B.ray_index[0], B.ray_index[1], (uint32_t)want_q, 30u, stream));
+    HIP_TRY(hipMalloc(&B.ray_sort_temp, rb ? rb : 16));
+    B.ray_sort_temp_bytes = rb;
     B.queue_cap = (uint32_t)want_q;
   }
   if (B.term_cap < want_t) {
@@ -127,12 +145,13 @@ static int render_wavefront(rt_dscene* d, const RowMap& rows, bool count, uint8_
   }
   HIP_TRY(hipMemsetAsync(B.counts, 0, 4 * sizeof(uint32_t), stream));
   RtQueues q;
-  q.in = nullptr; q.n_in = 0; q.out = B.queue[0]; q.out_count = B.counts + 0; q.out_cap = B.queue_cap;
-  q.term_keys = B.keys[0]; q.term_vals = B.vals[0]; q.term_count = B.counts + 2; q.term_cap = B.term_cap; q.enabled = 1;
+  q.in = nullptr; q.order = nullptr; q.n_in = 0; q.out = B.queue[0]; q.out_count = B.counts + 0; q.out_cap = B.queue_cap;
+  q.term_keys = B.keys[0]; q.term_vals = B.vals[0]; q.term_count = B.counts + 2; q.term_cap = B.term_cap; q.enabled = 1; q.path_bits = path_bits;
   rt_launch_wave_kernel(d->view, rows, true, count, d_rgb, d_ids, d_t, d->d_counters, tally, q, stream);
   HIP_TRY(hipGetLastError());
   uint32_t h[4];
   int cur = 0;
+  const float root_lo = -RT_INF / 4, root_side = RT_INF / 2;   // the octree's root cube (main.cu:25-31)
   for (int gen = 1; gen <= D + 1; gen++) {
     HIP_TRY(hipMemcpyAsync(h, B.counts, sizeof h, hipMemcpyDeviceToHost, stream));
     HIP_TRY(hipStreamSynchronize(stream));
@@ -140,6 +159,16 @@ static int render_wavefront(rt_dscene* d, const RowMap& rows, bool count, uint8_
     if (h[cur] == 0) break;
     HIP_TRY(hipMemsetAsync(B.counts + (cur ^ 1), 0, sizeof(uint32_t), stream));
     q.in = B.queue[cur]; q.n_in = h[cur]; q.out = B.queue[cur ^ 1]; q.out_count = B.counts + (cur ^ 1);
+    q.order = nullptr;
+    static const bool sort_rays = !(getenv("RT_AMD_SORT_RAYS") && atoi(getenv("RT_AMD_SORT_RAYS")) == 0);   // measurements
+    if (sort_rays && d->view.has_oct && h[cur] >= 4096) {   // the queue is put in an order that keeps similar rays together
+      // measured on the glass bunny: with a million rays a generation (4K) grouping by octant first wins (9.0 -> 7.0 ms, origin
+      // first 8.2); with a few hundred thousand (720p, 1080p) grouping by origin first does (4.1 -> 3.7 ms, 4.4 -> 3.9 ms)
+      rt_launch_ray_keys(B.queue[cur], h[cur], root_lo, root_side, h[cur] >= 600000u, B.ray_keys[0], B.ray_index[0], stream);
+      size_t rb = B.ray_sort_temp_bytes;
+      HIP_TRY(rt_sort_u32(B.ray_sort_temp, &rb, B.ray_keys[0], B.ray_keys[1], B.ray_index[0], B.ray_index[1], h[cur], 30u, stream));
+      q.order = B.ray_index[1];
+    }
     rt_launch_wave_kernel(d->view, rows, true, count, nullptr, nullptr, nullptr, d->d_counters, tally, q, stream);
     HIP_TRY(hipGetLastError());
     cur ^= 1;
@@ -148,11 +177,11 @@ static int render_wavefront(rt_dscene* d, const RowMap& rows, bool count, uint8_
   HIP_TRY(hipStreamSynchronize(stream));
   if (h[2] > B.term_cap || h[cur] != 0) return RT_OK;
   if (h[2] > 0) {
-    unsigned end_bit = RT_PATH_BITS;
-    while (end_bit < 64 && (n_out >> (end_bit - RT_PATH_BITS)) != 0) end_bit++;
+    unsigned end_bit = (unsigned)path_bits;   // only the bits that can be set are sorted on
+    while (end_bit < 64 && (n_out >> (end_bit - path_bits)) != 0) end_bit++;
     size_t bytes = B.sort_temp_bytes;
     HIP_TRY(rt_sort_terms(B.sort_temp, &bytes, B.keys[0], B.keys[1], B.vals[0], B.vals[1], h[2], end_bit, stream));
-    rt_launch_resolve_terms(B.keys[1], B.vals[1], h[2], d_rgb, stream);
+    rt_launch_resolve_terms(B.keys[1], B.vals[1], h[2], path_bits, d_rgb, stream);
     HIP_TRY(hipGetLastError());
   }
   *done = true;

@@ -448,7 +448,7 @@ __global__ __launch_bounds__(RT_BLOCK, BOUNCE ? RT_WAVES_PER_SIMD_BOUNCE : RT_WA
     const uint32_t gid = blockIdx.x * RT_BLOCK + tid;
     phase = PH_DONE; tr_e = {0.f, 0.f, 0.f}; tr_d = {0.f, 0.f, 1.f};
     if (gid < wf.n_in) {
-      const RtQRay& q = wf.in[gid];
+      const RtQRay& q = wf.in[wf.order ? wf.order[gid] : gid];
       tr_e = ld3(q.e); tr_d = ld3(q.d); sh.att = ld3(q.att);
       sh.level0 = q.level[0]; sh.level1 = q.level[1]; sh.level2 = q.level[2]; sh.nlevel = q.nlevel; sh.depth = q.depth;
       q_pixel = q.pixel; q_path = q.path;
@@ -474,7 +474,7 @@ __global__ __launch_bounds__(RT_BLOCK, BOUNCE ? RT_WAVES_PER_SIMD_BOUNCE : RT_WA
         q.att[0] = att.x; q.att[1] = att.y; q.att[2] = att.z;
         q.level[0] = sh.level0; q.level[1] = sh.level1; q.level[2] = sh.level2; q.nlevel = nlevel; q.depth = depth;
         q.pixel = q_pixel; q.pad = 0u;
-        q.path = q_path | ((unsigned long long)(RT_PATH_MAX_PUSHES - q_pushes) << (RT_PATH_BITS - 4 * depth));
+        q.path = q_path | ((unsigned long long)(RT_PATH_MAX_PUSHES - q_pushes) << (wf.path_bits - 4 * depth));
       }
       q_pushes++;
     } else if (BOUNCE) {
@@ -541,7 +541,7 @@ __global__ __launch_bounds__(RT_BLOCK, BOUNCE ? RT_WAVES_PER_SIMD_BOUNCE : RT_WA
             base = __builtin_amdgcn_readfirstlane(base);
             const uint32_t slot = base + rank;
             if (slot < wf.term_cap) {
-              wf.term_keys[slot] = ((unsigned long long)q_pixel << RT_PATH_BITS) | q_path;
+              wf.term_keys[slot] = ((unsigned long long)q_pixel << wf.path_bits) | q_path;
               wf.term_vals[slot] = RtTermRGB{sh.att.x * sh.colr.x, sh.att.y * sh.colr.y, sh.att.z * sh.colr.z, 0.f};
             }
             q_pending = true;
@@ -721,13 +721,13 @@ namespace {
 // One thread per term; the thread that holds the first term of a pixel adds up that pixel's terms in key order
 // (camera.cu:110-111: colour = colour + att * ray colour, starting from 0) and stores the pixel.
 __global__ __launch_bounds__(256) void resolve_terms(const unsigned long long* __restrict__ keys, const RtTermRGB* __restrict__ vals,
-                                                     uint32_t n, uint8_t* __restrict__ rgb) {
+                                                     uint32_t n, int path_bits, uint8_t* __restrict__ rgb) {
   const uint32_t i = blockIdx.x * 256u + threadIdx.x;
   if (i >= n) return;
-  const unsigned long long pixel = keys[i] >> RT_PATH_BITS;
-  if (i > 0u && (keys[i - 1] >> RT_PATH_BITS) == pixel) return;
+  const unsigned long long pixel = keys[i] >> path_bits;
+  if (i > 0u && (keys[i - 1] >> path_bits) == pixel) return;
   float r = 0.f, g = 0.f, b = 0.f;
-  for (uint32_t j = i; j < n && (keys[j] >> RT_PATH_BITS) == pixel; j++) {
+  for (uint32_t j = i; j < n && (keys[j] >> path_bits) == pixel; j++) {
     const RtTermRGB t = vals[j];
     r = r + t.r; g = g + t.g; b = b + t.b;
   }
@@ -736,7 +736,39 @@ __global__ __launch_bounds__(256) void resolve_terms(const unsigned long long* _
 }
 }  // namespace
 
-void rt_launch_resolve_terms(const unsigned long long* keys, const RtTermRGB* vals, uint32_t n, uint8_t* rgb, hipStream_t stream) {
+namespace {
+__device__ __forceinline__ uint32_t spread3(uint32_t v) {   // 9 bits -> every third bit
+  v = (v | (v << 16)) & 0x030000ffu;
+  v = (v | (v << 8)) & 0x0300f00fu;
+  v = (v | (v << 4)) & 0x030c30c3u;
+  v = (v | (v << 2)) & 0x09249249u;
+  return v;
+}
+__global__ __launch_bounds__(256) void ray_keys(const RtQRay* __restrict__ rays, uint32_t n, float root_lo, float inv_cell, int octant_first,
+                                                uint32_t* __restrict__ keys, uint32_t* __restrict__ index) {
+  const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+  if (i >= n) return;
+  const RtQRay& r = rays[i];
+  uint32_t cell[3];
+  for (int k = 0; k < 3; k++) {
+    const float g = (r.e[k] - root_lo) * inv_cell;
+    cell[k] = g > 0.f ? (g < 511.f ? (uint32_t)g : 511u) : 0u;   // (NaN -> 0)
+  }
+  const uint32_t oct = (r.d[0] < 0.f ? 1u : 0u) | (r.d[1] < 0.f ? 2u : 0u) | (r.d[2] < 0.f ? 4u : 0u);
+  const uint32_t morton = spread3(cell[0]) | (spread3(cell[1]) << 1) | (spread3(cell[2]) << 2);
+  keys[i] = octant_first ? ((oct << 27) | morton) : ((morton << 3) | oct);
+  index[i] = i;
+}
+}  // namespace
+
+void rt_launch_ray_keys(const RtQRay* rays, uint32_t n, float root_lo, float root_side, bool octant_first, uint32_t* keys, uint32_t* index,
+                        hipStream_t stream) {
   if (n == 0) return;
-  hipLaunchKernelGGL(resolve_terms, dim3((n + 255u) / 256u), dim3(256), 0, stream, keys, vals, n, rgb);
+  hipLaunchKernelGGL(ray_keys, dim3((n + 255u) / 256u), dim3(256), 0, stream, rays, n, root_lo, 512.f / root_side, octant_first ? 1 : 0, keys,
+                     index);
+}
+
+void rt_launch_resolve_terms(const unsigned long long* keys, const RtTermRGB* vals, uint32_t n, int path_bits, uint8_t* rgb, hipStream_t stream) {
+  if (n == 0) return;
+  hipLaunchKernelGGL(resolve_terms, dim3((n + 255u) / 256u), dim3(256), 0, stream, keys, vals, n, path_bits, rgb);
 }

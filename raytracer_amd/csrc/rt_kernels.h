@@ -68,7 +68,8 @@ struct BounceRay {   // the fields of DRay that survive a push (vector.cu:188-20
 // the queue rendered by the next launch with 64 of them per wave.  What each ray contributes is appended to a term list
 // with a key that sorts the terms of a pixel into the reference's processing order; a last kernel adds them up in that
 // order, so the float sums, and the bytes, are the reference's.
-//   path: 4 bits per tree level, level 1 in bits 35..32; the digit of the k-th push of a ray is 15 - k, so that a ray
+//   path: 4 bits per tree level, level 1 in the highest of the 4 * (ray depth limit) path bits; the digit of the k-th
+//         push of a ray is 15 - k, so that a ray
 //         pushed later (popped earlier by the LIFO stack) sorts first, a parent (shorter path, zero-padded) before its
 //         children, and a whole subtree before the next sibling: depth-first order, last pushed first = the stack's.
 struct RtQRay {   // 80 B
@@ -79,12 +80,13 @@ struct RtQRay {   // 80 B
   unsigned long long path;
 };
 struct RtTermRGB { float r, g, b, pad; };
-#define RT_PATH_BITS 36
 #define RT_PATH_MAX_PUSHES 15   // per ray
 struct RtQueues {
   const RtQRay* in; RtQRay* out; uint32_t* out_count;                 // in == nullptr: the pass that casts the primary rays
+  const uint32_t* order;                                              // lane i of the launch takes in[order[i]] (nullptr: in[i])
   unsigned long long* term_keys; RtTermRGB* term_vals; uint32_t* term_count;
   uint32_t n_in, out_cap, term_cap; int32_t enabled;
+  int32_t path_bits;   // 4 * ray depth limit: width of the path part of a term key, the pixel sits above it
 };
 
 // camera.cu:113-122: min(c, 1) * 255 truncated; NaN < 1 is false, so NaN -> 1 -> 255; negatives stored as 0
@@ -144,6 +146,14 @@ void rt_launch_wave_kernel(const RtDeviceView& view, const RowMap& rows, bool bo
 // Adds up the sorted terms of every pixel that has any, in key order, quantises and stores the pixel.
 hipError_t rt_sort_terms(void* temp, size_t* temp_bytes, const unsigned long long* keys_in, unsigned long long* keys_out,
                          const RtTermRGB* vals_in, RtTermRGB* vals_out, uint32_t n, unsigned end_bit, hipStream_t stream);
-void rt_launch_resolve_terms(const unsigned long long* keys, const RtTermRGB* vals, uint32_t n, uint8_t* rgb, hipStream_t stream);
+hipError_t rt_sort_u32(void* temp, size_t* temp_bytes, const uint32_t* keys_in, uint32_t* keys_out, const uint32_t* vals_in,
+                       uint32_t* vals_out, uint32_t n, unsigned end_bit, hipStream_t stream);
+// Coherence key of every queued ray (direction octant and Morton code of the origin on a 512^3 grid over the octree's
+// root cube, either of them in the high bits) and the identity permutation, to be sorted by key: waves then get rays
+// that start close together and head the same way, which is what the shared walk is good at.  Any order gives the
+// same image.
+void rt_launch_ray_keys(const RtQRay* rays, uint32_t n, float root_lo, float root_side, bool octant_first, uint32_t* keys, uint32_t* index,
+                        hipStream_t stream);
+void rt_launch_resolve_terms(const unsigned long long* keys, const RtTermRGB* vals, uint32_t n, int path_bits, uint8_t* rgb, hipStream_t stream);
 
 #endif

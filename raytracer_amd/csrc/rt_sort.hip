@@ -11,3 +11,8 @@ hipError_t rt_sort_terms(void* temp, size_t* temp_bytes, const unsigned long lon
                          const RtTermRGB* vals_in, RtTermRGB* vals_out, uint32_t n, unsigned end_bit, hipStream_t stream) {
   return rocprim::radix_sort_pairs(temp, *temp_bytes, keys_in, keys_out, vals_in, vals_out, (size_t)n, 0u, end_bit, stream);
 }
+
+hipError_t rt_sort_u32(void* temp, size_t* temp_bytes, const uint32_t* keys_in, uint32_t* keys_out, const uint32_t* vals_in,
+                       uint32_t* vals_out, uint32_t n, unsigned end_bit, hipStream_t stream) {
+  return rocprim::radix_sort_pairs(temp, *temp_bytes, keys_in, keys_out, vals_in, vals_out, (size_t)n, 0u, end_bit, stream);
+}
