@@ -445,9 +445,10 @@ __global__ __launch_bounds__(RT_BLOCK, BOUNCE ? RT_WAVES_PER_SIMD_BOUNCE : RT_WA
   // finished by the term list instead of by this lane
   uint32_t q_pixel = 0u; unsigned long long q_path = 0ull; int q_pushes = 0; bool q_pending = false;
   if (queued) {
-    const uint32_t gid = blockIdx.x * RT_BLOCK + tid;
+    const uint32_t per_wave = (uint32_t)wf.rays_per_wave;
+    const uint32_t gid = (blockIdx.x * (RT_BLOCK / 64) + (tid >> 6)) * per_wave + lane;
     phase = PH_DONE; tr_e = {0.f, 0.f, 0.f}; tr_d = {0.f, 0.f, 1.f};
-    if (gid < wf.n_in) {
+    if ((uint32_t)lane < per_wave && gid < wf.n_in) {
       const RtQRay& q = wf.in[wf.order ? wf.order[gid] : gid];
       tr_e = ld3(q.e); tr_d = ld3(q.d); sh.att = ld3(q.att);
       sh.level0 = q.level[0]; sh.level1 = q.level[1]; sh.level2 = q.level[2]; sh.nlevel = q.nlevel; sh.depth = q.depth;
@@ -705,7 +706,10 @@ void rt_launch_wave_kernel(const RtDeviceView& V, const RowMap& rows, bool bounc
                            float* ts, unsigned long long* counters, bool tally, const RtQueues& wf, hipStream_t stream) {
   const int tw = rows.small ? RT_TILE_W / 2 : RT_TILE_W, th = rows.small ? RT_TILE_H / 2 : RT_TILE_H;
   dim3 grid((V.cam.width + tw - 1) / tw, (rows.n_local + th - 1) / th), block(RT_BLOCK);
-  if (wf.in) { grid = dim3((wf.n_in + RT_BLOCK - 1) / RT_BLOCK, 1); bounce = true; }   // one queued ray per lane
+  if (wf.in) {   // one queued ray per lane (or per lane of the first quarter of each wave)
+    const uint32_t per_block = (RT_BLOCK / 64) * (uint32_t)wf.rays_per_wave;
+    grid = dim3((wf.n_in + per_block - 1) / per_block, 1); bounce = true;
+  }
 #define LAUNCH(B, C)                                                                                                             \
   hipLaunchKernelGGL((render_wave<B, C>), grid, block, 0, stream, V.cam, rows, V.wnodes, V.tri_leaf, V.tri_geom, V.tri_shade,     \
                      V.spheres, V.lights, V.materials, V.mat_index, V.mesh_mat_first, V.mesh_mat_count, V.n_spheres, V.n_lights, \

@@ -87,6 +87,7 @@ struct RtQueues {
   unsigned long long* term_keys; RtTermRGB* term_vals; uint32_t* term_count;
   uint32_t n_in, out_cap, term_cap; int32_t enabled;
   int32_t path_bits;   // 4 * ray depth limit: width of the path part of a term key, the pixel sits above it
+  int32_t rays_per_wave;   // 64, or 16 for a short queue: four times as many waves, each with a quarter of the walk
 };
 
 // camera.cu:113-122: min(c, 1) * 255 truncated; NaN < 1 is false, so NaN -> 1 -> 255; negatives stored as 0
