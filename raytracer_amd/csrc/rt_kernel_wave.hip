@@ -1,10 +1,11 @@
 // rt_kernel_wave.hip -- wave-synchronous render kernel for gfx950.
 //
-// A 64-lane wave owns an 8x8 pixel tile and walks the octree ONCE for all of its rays.  The
+// A 64-lane wave owns an 8x8 pixel tile (a 4x4 tile on small frames, or 64 / 16 queued bounce rays) and walks the
+// octree ONCE for all of its rays.  The
 // reference visits children in the fixed order 0..7 whatever the ray direction (ray.cu:40-50), so
 // every ray of the wave meets the nodes of the union of their subtrees in the same order; the wave
-// therefore keeps one traversal stack (node, next child, 64-bit mask of the lanes that entered the
-// node) instead of 64.  Consequences on CDNA4:
+// therefore keeps one traversal stack (branch, children still to test, 64-bit mask of the lanes that
+// entered the branch) instead of 64.  Consequences on CDNA4:
 //   * node and triangle records are addressed with wave-uniform indices, i.e. fetched through the
 //     scalar cache into SGPRs once per wave, and the loop control runs on the scalar unit;
 //   * a triangle is tested by all interested lanes in the same iteration, so the tests share
@@ -25,20 +26,13 @@ struct Tally { uint32_t rays, shadow, node, leaf, tri, sph, traced; uint32_t w[8
 // The wave's traversal stack lives in four VGPRs: entry i is held by lane i (depth <= 20 < 64) and is
 // written with a lane-select and read with v_readlane, whose lane index is wave-uniform.  No LDS, no memory latency.
 struct WaveStack {
-  uint32_t first, cur, mask_lo, mask_hi;   // index of child 0 of the branch, next child to test, lanes that entered it
+  uint32_t first, cur, mask_lo, mask_hi;   // index of child 0 of the branch, bit mask of its children still to test, lanes that entered it
 };
 
 typedef float v2f __attribute__((ext_vector_type(2)));   // two floats handled by one packed-fp32 instruction
 
 __device__ __forceinline__ uint32_t uni(uint32_t v) { return __builtin_amdgcn_readfirstlane(v); }
-__device__ __forceinline__ uint64_t uni64(uint64_t v) {
-  return ((uint64_t)uni((uint32_t)(v >> 32)) << 32) | uni((uint32_t)v);
-}
 
-// Closest hit (ray.cu:29-54) for all lanes of the wave at once.
-//   want   : this lane has a ray to trace
-//   stop_t : >= 0 for a shadow ray: the lane drops out as soon as its t falls below stop_t, because
-//            only "t < light distance" is consumed (ray.cu:70) and t never grows; < 0 = never
 // Wave-level path counters (how often each part of the walk runs) are kept by the instrumented variant, and by the
 // plain one too in a build with -DRT_PATH_COUNTS (measurements; off in the product).
 #ifdef RT_PATH_COUNTS
@@ -47,6 +41,10 @@ __device__ __forceinline__ uint64_t uni64(uint64_t v) {
 #define RT_PATHS_ON false
 #endif
 
+// Closest hit (ray.cu:29-54) for all lanes of the wave at once.
+//   want   : this lane has a ray to trace
+//   stop_t : >= 0 for a shadow ray: the lane drops out as soon as its t falls below stop_t, because
+//            only "t < light distance" is consumed (ray.cu:70) and t never grows; < 0 = never
 template <bool COUNT>
 __device__ __forceinline__ void trace_wave(const float4* __restrict__ nodes, int n_wnodes, const float4* __restrict__ tri_leaf,
                                            const RtSphere* __restrict__ spheres, int n_spheres, bool has_oct, bool want,
@@ -152,38 +150,38 @@ __device__ __forceinline__ void trace_wave(const float4* __restrict__ nodes, int
           und_m = mine_m & ~(acc_m | __builtin_amdgcn_ballot_w64(c_rej));
           if ((acc_m | und_m) != 0ull || rem == 0u) break;
         }
-        if (und_m) { na = rec(blk + NS * c_cur); nb = rec(blk + NS * c_cur + 1); }
-        else { na = float4{0.f, 0.f, 0.f, 0.f}; nb = float4{0.f, 0.f, __uint_as_float(r_first), __uint_as_float(r_meta)}; }
+        na = float4{0.f, 0.f, 0.f, 0.f}; nb = float4{0.f, 0.f, 0.f, 0.f};
+        if (und_m) { na = rec(blk + NS * c_cur); nb = rec(blk + NS * c_cur + 1); }   // the exact test wants the planes again
         nb.z = __uint_as_float(r_first); nb.w = __uint_as_float(r_meta);
       } else {
-      rem &= rem - 1u;
-      na = nx_a; nb = nx_b;
-      { const uint32_t c = (uint32_t)__builtin_ctz(rem | 0x100u); nx_a = rec(blk + NS * c); nx_b = rec(blk + NS * c + 1); }
-      if (PATHS && uni(__float_as_uint(nb.w)) != 0u) tl.w[1]++;
-      if (COUNT && ((mine_m >> lane) & 1ull)) tl.node++;
-      if (!any_zero) {
-        bool c_acc, c_rej;
-        rt_node_slab_fast(na.x, na.y, na.z, na.w, nb.x, nb.y, e, inv, hit.t, c_acc, c_rej);
-        acc_m = __builtin_amdgcn_ballot_w64(c_acc) & mine_m;
-        und_m = mine_m & ~(acc_m | __builtin_amdgcn_ballot_w64(c_rej));
-      } else if (zpat != 0u) {
-        bool c_acc = false, c_rej = false;
-        switch (zpat) {
-          case 1u: rt_node_slab_zero<true, false, false>(na.x, na.y, na.z, na.w, nb.x, nb.y, e, inv, hit.t, c_acc, c_rej); break;
-          case 2u: rt_node_slab_zero<false, true, false>(na.x, na.y, na.z, na.w, nb.x, nb.y, e, inv, hit.t, c_acc, c_rej); break;
-          case 3u: rt_node_slab_zero<true, true, false>(na.x, na.y, na.z, na.w, nb.x, nb.y, e, inv, hit.t, c_acc, c_rej); break;
-          case 4u: rt_node_slab_zero<false, false, true>(na.x, na.y, na.z, na.w, nb.x, nb.y, e, inv, hit.t, c_acc, c_rej); break;
-          case 5u: rt_node_slab_zero<true, false, true>(na.x, na.y, na.z, na.w, nb.x, nb.y, e, inv, hit.t, c_acc, c_rej); break;
-          default: rt_node_slab_zero<false, true, true>(na.x, na.y, na.z, na.w, nb.x, nb.y, e, inv, hit.t, c_acc, c_rej); break;
+        rem &= rem - 1u;
+        na = nx_a; nb = nx_b;
+        { const uint32_t c = (uint32_t)__builtin_ctz(rem | 0x100u); nx_a = rec(blk + NS * c); nx_b = rec(blk + NS * c + 1); }
+        if (PATHS && uni(__float_as_uint(nb.w)) != 0u) tl.w[1]++;
+        if (COUNT && ((mine_m >> lane) & 1ull)) tl.node++;
+        if (!any_zero) {
+          bool c_acc, c_rej;
+          rt_node_slab_fast(na.x, na.y, na.z, na.w, nb.x, nb.y, e, inv, hit.t, c_acc, c_rej);
+          acc_m = __builtin_amdgcn_ballot_w64(c_acc) & mine_m;
+          und_m = mine_m & ~(acc_m | __builtin_amdgcn_ballot_w64(c_rej));
+        } else if (zpat != 0u) {
+          bool c_acc = false, c_rej = false;
+          switch (zpat) {
+            case 1u: rt_node_slab_zero<true, false, false>(na.x, na.y, na.z, na.w, nb.x, nb.y, e, inv, hit.t, c_acc, c_rej); break;
+            case 2u: rt_node_slab_zero<false, true, false>(na.x, na.y, na.z, na.w, nb.x, nb.y, e, inv, hit.t, c_acc, c_rej); break;
+            case 3u: rt_node_slab_zero<true, true, false>(na.x, na.y, na.z, na.w, nb.x, nb.y, e, inv, hit.t, c_acc, c_rej); break;
+            case 4u: rt_node_slab_zero<false, false, true>(na.x, na.y, na.z, na.w, nb.x, nb.y, e, inv, hit.t, c_acc, c_rej); break;
+            case 5u: rt_node_slab_zero<true, false, true>(na.x, na.y, na.z, na.w, nb.x, nb.y, e, inv, hit.t, c_acc, c_rej); break;
+            default: rt_node_slab_zero<false, true, true>(na.x, na.y, na.z, na.w, nb.x, nb.y, e, inv, hit.t, c_acc, c_rej); break;
+          }
+          acc_m = __builtin_amdgcn_ballot_w64(c_acc) & mine_m;
+          und_m = mine_m & ~(acc_m | __builtin_amdgcn_ballot_w64(c_rej));
+        } else {
+          bool c_acc, c_und;
+          rt_node_slab_class2({na.x, na.z, nb.x}, {na.y, na.w, nb.y}, e, inv, hit.t, true, zmask, c_acc, c_und);
+          acc_m = __builtin_amdgcn_ballot_w64(c_acc) & mine_m;
+          und_m = __builtin_amdgcn_ballot_w64(c_und) & mine_m;
         }
-        acc_m = __builtin_amdgcn_ballot_w64(c_acc) & mine_m;
-        und_m = mine_m & ~(acc_m | __builtin_amdgcn_ballot_w64(c_rej));
-      } else {
-        bool c_acc, c_und;
-        rt_node_slab_class2({na.x, na.z, nb.x}, {na.y, na.w, nb.y}, e, inv, hit.t, true, zmask, c_acc, c_und);
-        acc_m = __builtin_amdgcn_ballot_w64(c_acc) & mine_m;
-        und_m = __builtin_amdgcn_ballot_w64(c_und) & mine_m;
-      }
       }
       if (und_m) {
         if (PATHS) tl.w[2]++;
