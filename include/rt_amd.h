@@ -113,8 +113,11 @@ void rt_dscene_destroy(rt_dscene* d);
  *   d_ids : optional DEVICE pointer, W*H int32 primary-hit primitive ids (NULL to skip).
  *   d_t   : optional DEVICE pointer, W*H float primary-hit distance (64 on a miss).
  *   stream: hipStream_t (NULL = default stream).  The call is asynchronous
- *           unless RT_RENDER_TIME is set or `stats` is non-NULL (stats are
- *           read back, which synchronises the stream). */
+ *           unless RT_RENDER_TIME is set, `stats` is non-NULL (stats are
+ *           read back, which synchronises the stream) or the scene's bounce
+ *           rays go through queues (RT_RENDER_QUEUED; queue fills are read back).
+ * An rt_dscene owns one set of counters and queue buffers: calls on the same
+ * rt_dscene must not overlap (use one rt_dscene per stream that renders concurrently). */
 int rt_render_rows(rt_dscene* d, int row_begin, int row_end, uint8_t* d_rgb, int32_t* d_ids, float* d_t,
                    void* stream, unsigned flags, rt_stats* stats);
 
