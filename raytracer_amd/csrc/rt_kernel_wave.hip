@@ -368,7 +368,10 @@ __device__ __forceinline__ void unpark(ShadeState<BOUNCE>& s, const float* lds) 
 #undef GET_I
 }
 
-template <bool BOUNCE, bool COUNT>
+// BOUNCE: the scene has reflective or dielectric materials; COUNT: instrumented; QUEUES (with BOUNCE): bounce rays leave
+// through / arrive from the generation queues instead of living on the lane's stack (a variant of its own, so that
+// the stacked kernel does not carry the queue code in its registers).
+template <bool BOUNCE, bool COUNT, bool QUEUES>
 __global__ __launch_bounds__(RT_BLOCK, BOUNCE ? RT_WAVES_PER_SIMD_BOUNCE : RT_WAVES_PER_SIMD) void render_wave(
     const RtCamera cam, const RowMap rows, const float4* __restrict__ nodes, const float4* __restrict__ tri_leaf,
     const float4* __restrict__ tri_geom, const float4* __restrict__ tri_shade, const RtSphere* __restrict__ spheres,
@@ -414,8 +417,8 @@ __global__ __launch_bounds__(RT_BLOCK, BOUNCE ? RT_WAVES_PER_SIMD_BOUNCE : RT_WA
   RtVec3 tr_e, tr_d;        // ray being traced
   float tr_stop = -1.f;     // >= 0: shadow ray, length to the light
   int phase;
-  const bool wavefront = BOUNCE && wf.enabled != 0;        // bounce rays leave through the queue
-  const bool queued = BOUNCE && wf.in != nullptr;           // this launch renders a queue of bounce rays, one per lane
+  const bool wavefront = BOUNCE && QUEUES;                    // bounce rays leave through the queue
+  const bool queued = BOUNCE && QUEUES && wf.in != nullptr;   // this launch renders a queue of bounce rays, one per lane
   if (!queued) {
     const Pixel px0 = pixel_of(tid);
     phase = px0.valid ? PH_CLOSEST : PH_DONE;
@@ -708,14 +711,15 @@ void rt_launch_wave_kernel(const RtDeviceView& V, const RowMap& rows, bool bounc
     const uint32_t per_block = (RT_BLOCK / 64) * (uint32_t)wf.rays_per_wave;
     grid = dim3((wf.n_in + per_block - 1) / per_block, 1); bounce = true;
   }
-#define LAUNCH(B, C)                                                                                                             \
-  hipLaunchKernelGGL((render_wave<B, C>), grid, block, 0, stream, V.cam, rows, V.wnodes, V.tri_leaf, V.tri_geom, V.tri_shade,     \
+#define LAUNCH(B, C, Q)                                                                                                          \
+  hipLaunchKernelGGL((render_wave<B, C, Q>), grid, block, 0, stream, V.cam, rows, V.wnodes, V.tri_leaf, V.tri_geom, V.tri_shade,  \
                      V.spheres, V.lights, V.materials, V.mat_index, V.mesh_mat_first, V.mesh_mat_count, V.n_spheres, V.n_lights, \
                      V.has_oct, V.n_wnodes, rgb, ids, ts, counters, tally ? 1 : 0, wf)
-  if (bounce && count) LAUNCH(true, true);
-  else if (bounce) LAUNCH(true, false);
-  else if (count) LAUNCH(false, true);
-  else LAUNCH(false, false);
+  if (wf.enabled) { if (count) LAUNCH(true, true, true); else LAUNCH(true, false, true); }
+  else if (bounce && count) LAUNCH(true, true, false);
+  else if (bounce) LAUNCH(true, false, false);
+  else if (count) LAUNCH(false, true, false);
+  else LAUNCH(false, false, false);
 #undef LAUNCH
 }
 
