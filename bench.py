@@ -83,8 +83,10 @@ def cpu_baseline(args, threads):
         rows += r1 - r0
     dt = time.perf_counter() - t0
     return {"value": rays / dt / 1e6, "unit": "Mrays/s", "cores": threads, "kind": "port",
-            "sample": "every %d-th 16-row band of the same %dx%d frame: %d rows, %d rays in %.2f s" %
-                      (args.cpu_band_stride, args.width, args.height, rows, rays, dt)}
+            "sample": ("the whole %dx%d frame: %d rows, %d rays in %.2f s" % (args.width, args.height, rows, rays, dt))
+                      if args.cpu_band_stride == 1 else
+                      ("every %d-th 16-row band of the same %dx%d frame: %d rows, %d rays in %.2f s" %
+                       (args.cpu_band_stride, args.width, args.height, rows, rays, dt))}
 
 
 def main():
