@@ -21,6 +21,16 @@
 
 namespace {
 
+// Workgroup of this kernel: waves are independent of each other (no barrier, no shared data), so a workgroup is a
+// single wave: the slot of a finished wave is then refilled at once instead of waiting for the other waves of a
+// larger workgroup to finish (tiles differ a lot in cost).
+#ifndef RT_WBLOCK
+#define RT_WBLOCK 64
+#endif
+#define RT_WAVES_X (RT_WBLOCK >= 128 ? 2 : 1)
+#define RT_WTILE_W (8 * RT_WAVES_X)
+#define RT_WTILE_H (8 * (RT_WBLOCK / 64) / RT_WAVES_X)
+
 struct Tally { uint32_t rays, shadow, node, leaf, tri, sph, traced; uint32_t w[8]; };   // w: wave-level path counts (lane 0, instrumented variant)
 
 // The wave's traversal stack lives in four VGPRs: entry i is held by lane i (depth <= 20 < 64) and is
@@ -100,6 +110,9 @@ __device__ __forceinline__ void trace_wave(const float4* __restrict__ nodes, int
     // always requested as soon as it is known (next sibling: before the current child is classified; first child of
     // a branch: on descent or ascent), so its latency hides behind the classification.
     float4 nx_a = {0, 0, 0, 0}, nx_b = {0, 0, 0, 0};
+    // margin that no node of this tree exceeds for this ray (the root's planes bound every node's)
+    float neg_eb = 0.f;
+    if (presorted) { const float4 ra = rec(cnodes), rb = rec(cnodes + 1); neg_eb = -rt_slab_margin_bound(ra.x, ra.y, ra.z, ra.w, rb.x, rb.y, e, inv, hit.t); }
     cnode_ptr blk = cnodes + NS * top_first;   // records of the current branch's children
     { const uint32_t c = (uint32_t)__builtin_ctz(rem | 0x100u); nx_a = rec(blk + NS * c); nx_b = rec(blk + NS * c + 1); }
     // `mine_m` = lanes that entered the current branch and are still undecided.  It only changes when the branch changes or
@@ -144,10 +157,20 @@ __device__ __forceinline__ void trace_wave(const float4* __restrict__ nodes, int
           }
           if (PATHS && r_meta != 0u) tl.w[1]++;
           if (COUNT && ((mine_m >> lane) & 1ull)) tl.node++;   // w[1]: iterations the plain variant also makes
-          bool c_acc, c_rej;
-          rt_node_slab_sorted(dx0 * inv.x, dx1 * inv.x, dy0 * inv.y, dy1 * inv.y, dz0 * inv.z, dz1 * inv.z, hit.t, c_acc, c_rej);
-          acc_m = __builtin_amdgcn_ballot_w64(c_acc) & mine_m;
-          und_m = mine_m & ~(acc_m | __builtin_amdgcn_ballot_w64(c_rej));
+          const float tx0 = dx0 * inv.x, tx1 = dx1 * inv.x, ty0 = dy0 * inv.y, ty1 = dy1 * inv.y, tz0 = dz0 * inv.z, tz1 = dz1 * inv.z;
+          const RtSlabHead hd = rt_node_slab_head(tx0, tx1, ty0, ty1, tz0, tz1, hit.t);
+          // Most children are missed by every ray of the wave, and by far: those are settled against the ray's largest
+          // possible margin, without working out the margin of this node.
+          acc_m = 0ull; und_m = 0ull;
+          if ((mine_m & ~__builtin_amdgcn_ballot_w64(hd.r < neg_eb)) != 0ull) {
+#ifdef RT_PATH_QUICK
+            tl.w[3]++;
+#endif
+            bool c_acc, c_rej;
+            rt_node_slab_tail(hd, tx0, tx1, ty0, ty1, tz0, tz1, hit.t, c_acc, c_rej);
+            acc_m = __builtin_amdgcn_ballot_w64(c_acc) & mine_m;
+            und_m = mine_m & ~(acc_m | __builtin_amdgcn_ballot_w64(c_rej));
+          }
           if ((acc_m | und_m) != 0ull || rem == 0u) break;
         }
         na = float4{0.f, 0.f, 0.f, 0.f}; nb = float4{0.f, 0.f, 0.f, 0.f};
@@ -350,8 +373,8 @@ struct ShadeState {
 template <bool BOUNCE>
 __device__ __forceinline__ void park(const ShadeState<BOUNCE>& s, float* lds) {
   uint32_t* ldu = (uint32_t*)lds;
-#define PUT_F(k, f) lds[(k) * RT_BLOCK] = s.f;
-#define PUT_I(k, f) ldu[(k) * RT_BLOCK] = (uint32_t)s.f;
+#define PUT_F(k, f) lds[(k) * RT_WBLOCK] = s.f;
+#define PUT_I(k, f) ldu[(k) * RT_WBLOCK] = (uint32_t)s.f;
   RT_SHADE_FLOATS(PUT_F) RT_SHADE_INTS(PUT_I)
   if (BOUNCE) { RT_SHADE_BOUNCE_FLOATS(PUT_F) RT_SHADE_BOUNCE_INTS(PUT_I) }
 #undef PUT_F
@@ -360,8 +383,8 @@ __device__ __forceinline__ void park(const ShadeState<BOUNCE>& s, float* lds) {
 template <bool BOUNCE>
 __device__ __forceinline__ void unpark(ShadeState<BOUNCE>& s, const float* lds) {
   const uint32_t* ldu = (const uint32_t*)lds;
-#define GET_F(k, f) s.f = lds[(k) * RT_BLOCK];
-#define GET_I(k, f) s.f = (decltype(s.f))ldu[(k) * RT_BLOCK];
+#define GET_F(k, f) s.f = lds[(k) * RT_WBLOCK];
+#define GET_I(k, f) s.f = (decltype(s.f))ldu[(k) * RT_WBLOCK];
   RT_SHADE_FLOATS(GET_F) RT_SHADE_INTS(GET_I)
   if (BOUNCE) { RT_SHADE_BOUNCE_FLOATS(GET_F) RT_SHADE_BOUNCE_INTS(GET_I) }
 #undef GET_F
@@ -372,7 +395,7 @@ __device__ __forceinline__ void unpark(ShadeState<BOUNCE>& s, const float* lds) 
 // through / arrive from the generation queues instead of living on the lane's stack (a variant of its own, so that
 // the stacked kernel does not carry the queue code in its registers).
 template <bool BOUNCE, bool COUNT, bool QUEUES>
-__global__ __launch_bounds__(RT_BLOCK, BOUNCE ? RT_WAVES_PER_SIMD_BOUNCE : RT_WAVES_PER_SIMD) void render_wave(
+__global__ __launch_bounds__(RT_WBLOCK, BOUNCE ? RT_WAVES_PER_SIMD_BOUNCE : RT_WAVES_PER_SIMD) void render_wave(
     const RtCamera cam, const RowMap rows, const float4* __restrict__ nodes, const float4* __restrict__ tri_leaf,
     const float4* __restrict__ tri_geom, const float4* __restrict__ tri_shade, const RtSphere* __restrict__ spheres,
     const RtLight* __restrict__ lights, const RtMaterial* __restrict__ materials, const int32_t* __restrict__ mat_index,
@@ -380,8 +403,8 @@ __global__ __launch_bounds__(RT_BLOCK, BOUNCE ? RT_WAVES_PER_SIMD_BOUNCE : RT_WA
     uint8_t* __restrict__ rgb, int32_t* __restrict__ ids, float* __restrict__ ts, unsigned long long* __restrict__ counters_all, int tally,
     const RtQueues wf) {
   unsigned long long* const counters = counters_all + ((blockIdx.x + blockIdx.y) & (RT_COUNTER_COPIES - 1)) * RT_COUNTER_STRIDE;
-  __shared__ float parked[ShadeState<BOUNCE>::WORDS * RT_BLOCK];
-  __shared__ uint32_t pack[RT_BLOCK / 64][48];
+  __shared__ float parked[ShadeState<BOUNCE>::WORDS * RT_WBLOCK];
+  __shared__ uint32_t pack[RT_WBLOCK / 64][48];
   const int tid = threadIdx.x, lane = tid & 63;
   float* my_park = &parked[tid];
   WaveStack st = {0u, 0u, 0u, 0u};
@@ -395,11 +418,11 @@ __global__ __launch_bounds__(RT_BLOCK, BOUNCE ? RT_WAVES_PER_SIMD_BOUNCE : RT_WA
     const int w = t >> 6, l = t & 63;
     Pixel p;
     if (rows.small) {
-      p.col = blockIdx.x * (RT_TILE_W / 2) + (w & 1) * 4 + (l & 3);
-      p.lrow = blockIdx.y * (RT_TILE_H / 2) + (w >> 1) * 4 + ((l >> 2) & 3);
+      p.col = blockIdx.x * (RT_WTILE_W / 2) + (w % RT_WAVES_X) * 4 + (l & 3);
+      p.lrow = blockIdx.y * (RT_WTILE_H / 2) + (w / RT_WAVES_X) * 4 + ((l >> 2) & 3);
     } else {
-      p.col = blockIdx.x * RT_TILE_W + (w & 1) * 8 + (l & 7);
-      p.lrow = blockIdx.y * RT_TILE_H + (w >> 1) * 8 + (l >> 3);
+      p.col = blockIdx.x * RT_WTILE_W + (w % RT_WAVES_X) * 8 + (l & 7);
+      p.lrow = blockIdx.y * RT_WTILE_H + (w / RT_WAVES_X) * 8 + (l >> 3);
     }
     p.row = rows.row0 + (p.lrow / rows.band_rows) * rows.band_stride + p.lrow % rows.band_rows;
     p.orow = rows.compact ? p.lrow : p.row;
@@ -408,6 +431,11 @@ __global__ __launch_bounds__(RT_BLOCK, BOUNCE ? RT_WAVES_PER_SIMD_BOUNCE : RT_WA
   };
   Tally tl = {0, 0, 0, 0, 0, 0, 0, {0, 0, 0, 0, 0, 0, 0, 0}};
   const RtCamera& c = cam;
+#ifdef RT_WAVE_TIMES
+  // Diagnostic build: every wave leaves (start, end) of its life on the 100 MHz clock and where it ran in the `t`
+  // output, four words per wave in launch order (tools/wave_times.py); the per-pixel t is not written then.
+  const unsigned long long wt_start = __builtin_amdgcn_s_memrealtime();
+#endif
 
   // view handed to the helpers of rt_kernels.h
   RtDeviceView S;
@@ -447,7 +475,7 @@ __global__ __launch_bounds__(RT_BLOCK, BOUNCE ? RT_WAVES_PER_SIMD_BOUNCE : RT_WA
   uint32_t q_pixel = 0u; unsigned long long q_path = 0ull; int q_pushes = 0; bool q_pending = false;
   if (queued) {
     const uint32_t per_wave = (uint32_t)wf.rays_per_wave;
-    const uint32_t gid = (blockIdx.x * (RT_BLOCK / 64) + (tid >> 6)) * per_wave + lane;
+    const uint32_t gid = (blockIdx.x * (RT_WBLOCK / 64) + (tid >> 6)) * per_wave + lane;
     phase = PH_DONE; tr_e = {0.f, 0.f, 0.f}; tr_d = {0.f, 0.f, 1.f};
     if ((uint32_t)lane < per_wave && gid < wf.n_in) {
       const RtQRay& q = wf.in[wf.order ? wf.order[gid] : gid];
@@ -510,7 +538,9 @@ __global__ __launch_bounds__(RT_BLOCK, BOUNCE ? RT_WAVES_PER_SIMD_BOUNCE : RT_WA
           const Pixel px = pixel_of(tid);
           const size_t p = (size_t)px.orow * W + px.col;
           if (ids) ids[p] = h.prim;
+#ifndef RT_WAVE_TIMES
           if (ts) ts[p] = h.t;
+#endif
         }
       }
       sh.colr = {0.f, 0.f, 0.f};
@@ -687,6 +717,14 @@ __global__ __launch_bounds__(RT_BLOCK, BOUNCE ? RT_WAVES_PER_SIMD_BOUNCE : RT_WA
     }
   }
   (void)q_pending;
+#ifdef RT_WAVE_TIMES
+  if (ts && !queued && lane == 0) {
+    const unsigned long long wt_end = __builtin_amdgcn_s_memrealtime();
+    const uint32_t hw = __builtin_amdgcn_s_getreg((31 << 11) | (0 << 6) | 4), xcc = __builtin_amdgcn_s_getreg((31 << 11) | (0 << 6) | 20);
+    uint32_t* o = (uint32_t*)ts + 4 * (size_t)((blockIdx.y * gridDim.x + blockIdx.x) * (RT_WBLOCK / 64) + (tid >> 6));
+    o[0] = (uint32_t)wt_start; o[1] = (uint32_t)wt_end; o[2] = hw; o[3] = xcc;
+  }
+#endif
 
   // work counters: wave reduction, one atomic per wave and counter
   if (!tally) return;   // nobody asked for statistics
@@ -705,10 +743,10 @@ __global__ __launch_bounds__(RT_BLOCK, BOUNCE ? RT_WAVES_PER_SIMD_BOUNCE : RT_WA
 
 void rt_launch_wave_kernel(const RtDeviceView& V, const RowMap& rows, bool bounce, bool count, uint8_t* rgb, int32_t* ids,
                            float* ts, unsigned long long* counters, bool tally, const RtQueues& wf, hipStream_t stream) {
-  const int tw = rows.small ? RT_TILE_W / 2 : RT_TILE_W, th = rows.small ? RT_TILE_H / 2 : RT_TILE_H;
-  dim3 grid((V.cam.width + tw - 1) / tw, (rows.n_local + th - 1) / th), block(RT_BLOCK);
+  const int tw = rows.small ? RT_WTILE_W / 2 : RT_WTILE_W, th = rows.small ? RT_WTILE_H / 2 : RT_WTILE_H;
+  dim3 grid((V.cam.width + tw - 1) / tw, (rows.n_local + th - 1) / th), block(RT_WBLOCK);
   if (wf.in) {   // one queued ray per lane (or per lane of the first quarter of each wave)
-    const uint32_t per_block = (RT_BLOCK / 64) * (uint32_t)wf.rays_per_wave;
+    const uint32_t per_block = (RT_WBLOCK / 64) * (uint32_t)wf.rays_per_wave;
     grid = dim3((wf.n_in + per_block - 1) / per_block, 1); bounce = true;
   }
 #define LAUNCH(B, C, Q)                                                                                                          \

@@ -361,18 +361,42 @@ RT_HD int rt_node_slab_class(const RtVec3& lo, const RtVec3& hi, const RtVec3& e
 // kernel's node records.  acc / rej equal "class > 0" / "class < 0" of rt_node_slab_class; neither = undecided.
 // (tc - T = -(T - tc) exactly, and max3(-a,-b,-c) > E <=> min3(a,b,c) < -E; a NaN can only come from an infinite
 // plane distance, which makes E infinite and both comparisons false.)
-RT_HD void rt_node_slab_sorted(float nx, float fx, float ny, float fy, float nz, float fz, float T, bool& acc, bool& rej) {
-  const float tN = rt_max3(nx, ny, nz), tN2 = rt_med3(nx, ny, nz);
-  const float tF = rt_min3(fx, fy, fz), tF2 = rt_med3(fx, fy, fz);
+// The classification comes in two steps.  The head holds what a certain rejection needs; the tail adds the margin and
+// the acceptance.  A caller that knows an upper bound Eb >= E for its ray (rt_slab_margin_bound) may conclude
+// "rejected" from head.r < -Eb alone and skip the tail: that is the tail's own rejection test with a larger margin.
+struct RtSlabHead { float tN, tF, span, tc, x, r; bool front; };
+RT_HD RtSlabHead rt_node_slab_head(float nx, float fx, float ny, float fy, float nz, float fz, float T) {
+  RtSlabHead h;
+  h.tN = rt_max3(nx, ny, nz);
+  h.tF = rt_min3(fx, fy, fz);
+  h.span = h.tF - h.tN;
+  h.front = h.tN > 0.f;
+  h.tc = h.front ? h.tN : h.tF;
+  h.x = T - h.tc;
+  h.r = rt_min3(h.span, h.tF, h.x);
+  return h;
+}
+RT_HD void rt_node_slab_tail(const RtSlabHead& h, float nx, float fx, float ny, float fy, float nz, float fz, float T, bool& acc, bool& rej) {
+  const float tN2 = rt_med3(nx, ny, nz), tF2 = rt_med3(fx, fy, fz);
   const float M = fmaxf(rt_max3(fx, fy, fz), -rt_min3(nx, ny, nz));   // = max |t| over the six planes, as near <= far per axis
   const float E = RT_SLAB_EPS * (M + T);
-  const float span = tF - tN;
-  const bool front = tN > 0.f;
-  const float tc = front ? tN : tF;
-  const float gap = front ? tN - tN2 : tF2 - tF;
-  const float x = T - tc;
-  acc = fminf(rt_min3(x, gap, span), tc) > E;
-  rej = rt_min3(span, tF, x) < -E;
+  const float gap = h.front ? h.tN - tN2 : tF2 - h.tF;
+  acc = fminf(rt_min3(h.x, gap, h.span), h.tc) > E;
+  rej = h.r < -E;
+}
+RT_HD void rt_node_slab_sorted(float nx, float fx, float ny, float fy, float nz, float fz, float T, bool& acc, bool& rej) {
+  const RtSlabHead h = rt_node_slab_head(nx, fx, ny, fy, nz, fz, T);
+  rt_node_slab_tail(h, nx, fx, ny, fy, nz, fz, T, acc, rej);
+}
+// Upper bound of the margin E of the classification for every node inside the cube whose planes are (lo, hi) per axis
+// and every T <= T0: a plane p of such a node has |fl(p - e)| <= max(|fl(lo - e)|, |fl(hi - e)|) (rounding is monotone),
+// products and sums with the same partners keep the order, so M <= the largest of the three bounds and
+// fl(EPS fl(M + T)) <= fl(EPS fl(bound + T0)).
+RT_HD float rt_slab_margin_bound(float lox, float hix, float loy, float hiy, float loz, float hiz, const RtVec3& e, const RtVec3& inv, float T0) {
+  const float mx = fmaxf(fabsf(lox - e.x), fabsf(hix - e.x)) * fabsf(inv.x);
+  const float my = fmaxf(fabsf(loy - e.y), fabsf(hiy - e.y)) * fabsf(inv.y);
+  const float mz = fmaxf(fabsf(loz - e.z), fabsf(hiz - e.z)) * fabsf(inv.z);
+  return RT_SLAB_EPS * (rt_max3(mx, my, mz) + T0);
 }
 RT_HD void rt_node_slab_fast(float lox, float hix, float loy, float hiy, float loz, float hiz, const RtVec3& e, const RtVec3& inv,
                              float T, bool& acc, bool& rej) {

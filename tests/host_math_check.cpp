@@ -19,7 +19,7 @@
 #include "../include/rt_amd.h"
 #include "../raytracer_amd/csrc/rt_math.h"
 
-static uint64_t n_node = 0, n_tri = 0, n_bad = 0, n_cand = 0, n_acc = 0, n_zero = 0, n_amb = 0, n_zero_axis = 0;
+static uint64_t n_node = 0, n_tri = 0, n_bad = 0, n_cand = 0, n_acc = 0, n_zero = 0, n_amb = 0, n_zero_axis = 0, n_quick = 0;
 
 static bool check_node(const RtVec3& ini, const RtVec3& end, const RtVec3& e, const RtVec3& d, float T) {
   const bool lit = rt_node_accept_literal(ini, end, e, d, T);
@@ -67,6 +67,21 @@ static bool check_node(const RtVec3& ini, const RtVec3& end, const RtVec3& e, co
         if (n_bad < 10) printf("SLAB PRESORTED/FAST DIFFER %d %d vs %d %d\n", (int)pa, (int)pr, (int)fa, (int)fr);
         n_bad++;
       }
+      // the early rejection against a margin bound taken from an enclosing cube may only fire where the full form rejects
+      const float nx = ((d.x < 0 ? hi.x : lo.x) - e.x) * inv.x, fx = ((d.x < 0 ? lo.x : hi.x) - e.x) * inv.x;
+      const float ny = ((d.y < 0 ? hi.y : lo.y) - e.y) * inv.y, fy = ((d.y < 0 ? lo.y : hi.y) - e.y) * inv.y;
+      const float nz = ((d.z < 0 ? hi.z : lo.z) - e.z) * inv.z, fz = ((d.z < 0 ? lo.z : hi.z) - e.z) * inv.z;
+      const RtSlabHead hd = rt_node_slab_head(nx, fx, ny, fy, nz, fz, T);
+      const bool in_root = lo.x >= -16.f && hi.x <= 16.f && lo.y >= -16.f && hi.y <= 16.f && lo.z >= -16.f && hi.z <= 16.f;
+      const float b_self = rt_slab_margin_bound(lo.x, hi.x, lo.y, hi.y, lo.z, hi.z, e, inv, 64.f);
+      const float b_root = rt_slab_margin_bound(-16.f, 16.f, -16.f, 16.f, -16.f, 16.f, e, inv, 64.f);
+      const bool q_self = T <= 64.f && hd.r < -b_self, q_root = T <= 64.f && in_root && hd.r < -b_root;
+      n_quick += q_root;
+      if ((q_self || q_root) && !pr) {
+        if (n_bad < 10) printf("SLAB EARLY REJECTION WITHOUT REJECTION self %d root %d\n", (int)q_self, (int)q_root);
+        n_bad++;
+      }
+      if (in_root && b_root < b_self) { if (n_bad < 10) printf("ROOT MARGIN BELOW NODE MARGIN\n"); n_bad++; }
     }
     if ((cls > 0 && !lit) || (cls < 0 && lit)) {
       if (n_bad < 10) printf("SLAB CONTRADICTION cls %d lit %d ini %.9g %.9g %.9g end %.9g %.9g %.9g e %.9g %.9g %.9g d %.9g %.9g %.9g T %.9g\n", cls, lit,
@@ -166,7 +181,7 @@ static int run_scene(int ac, char** av) {
       trace(T, {P.x + ls[k].x * 0.001f, P.y + ls[k].y * 0.001f, P.z + ls[k].z * 0.001f}, ls[k], sh);
     }
   }
-  printf("checked %llu %llu mismatches %llu candidates %llu score_zero %llu slab_undecided %llu zero_axis_tests %llu\n", (unsigned long long)n_node, (unsigned long long)n_tri, (unsigned long long)n_bad, (unsigned long long)n_cand, (unsigned long long)n_zero, (unsigned long long)n_amb, (unsigned long long)n_zero_axis);
+  printf("checked %llu %llu mismatches %llu candidates %llu score_zero %llu slab_undecided %llu zero_axis_tests %llu early_rejections %llu\n", (unsigned long long)n_node, (unsigned long long)n_tri, (unsigned long long)n_bad, (unsigned long long)n_cand, (unsigned long long)n_zero, (unsigned long long)n_amb, (unsigned long long)n_zero_axis, (unsigned long long)n_quick);
   return n_bad ? 1 : 0;
 }
 
@@ -209,7 +224,7 @@ static int run_random(int ac, char** av) {
     }
     check_node(ini, end, e, d, T);
   }
-  printf("checked %llu %llu mismatches %llu accepted %llu score_zero %llu slab_undecided %llu zero_axis_tests %llu\n", (unsigned long long)n_node, (unsigned long long)n_tri, (unsigned long long)n_bad, (unsigned long long)n_acc, (unsigned long long)n_zero, (unsigned long long)n_amb, (unsigned long long)n_zero_axis);
+  printf("checked %llu %llu mismatches %llu accepted %llu score_zero %llu slab_undecided %llu zero_axis_tests %llu early_rejections %llu\n", (unsigned long long)n_node, (unsigned long long)n_tri, (unsigned long long)n_bad, (unsigned long long)n_acc, (unsigned long long)n_zero, (unsigned long long)n_amb, (unsigned long long)n_zero_axis, (unsigned long long)n_quick);
   return n_bad ? 1 : 0;
 }
 

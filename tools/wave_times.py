@@ -1,0 +1,35 @@
+#!/usr/bin/env python3
+"""Life spans of the waves of one frame (diagnostic build: tools/build_variant.sh times -DRT_WAVE_TIMES, selected with
+RT_AMD_LIB): how many waves are resident over time, how long waves live, how evenly the XCDs finish.
+   RT_AMD_LIB=build/variants/librt_amd_times.so python tools/wave_times.py [scene] [WxH]   (from the repository root)"""
+import sys
+sys.path.insert(0, '.')
+import numpy as np
+import raytracer_amd as rt
+
+scene = sys.argv[1] if len(sys.argv) > 1 else "meshDragon"
+w, h = (int(x) for x in (sys.argv[2] if len(sys.argv) > 2 else "3840x2160").split("x"))
+ds = rt.DeviceScene(rt.Scene("scenes/%s.json" % scene, w, h, 3))
+for _ in range(2):
+    rgb, ids, ts, st = ds.render_host(flags=rt.RT_RENDER_TIME)
+n = ((w + 7) // 8) * ((h + 7) // 8)
+raw = ts.view(np.uint32).reshape(-1)[:4 * n].reshape(n, 4)
+start = raw[:, 0].astype(np.int64); end = raw[:, 1].astype(np.int64)
+end = np.where(end < start, end + (1 << 32), end)
+t0 = start.min(); start -= t0; end -= t0
+total = end.max()
+print("kernel_ms %.3f; first wave start to last wave end: %.3f ms (100 MHz clock); %d waves" % (st["kernel_ms"], total / 1e5, n))
+dur = (end - start) / 100.0
+print("wave life (us): mean %.1f median %.1f p90 %.1f p99 %.1f max %.1f" % (dur.mean(), np.median(dur), np.percentile(dur, 90), np.percentile(dur, 99), dur.max()))
+# resident waves over time, in 20 slices
+edges = np.linspace(0, total, 21)
+print("slice  resident waves (avg)   waves started   waves ended")
+for k in range(20):
+    a, b = edges[k], edges[k + 1]
+    overlap = np.clip(np.minimum(end, b) - np.maximum(start, a), 0, None).sum() / (b - a)
+    print("%5d  %12.0f  %14d  %12d" % (k, overlap, ((start >= a) & (start < b)).sum(), ((end > a) & (end <= b)).sum()))
+xcc = raw[:, 3] & 0xf
+print("per XCD: waves, busy wave-ms, last end (ms)")
+for x in np.unique(xcc):
+    m = xcc == x
+    print("  xcd %d: %7d  %8.2f  %6.3f" % (x, m.sum(), dur[m].sum() / 1e3, end[m].max() / 1e5))
