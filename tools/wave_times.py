@@ -33,3 +33,19 @@ print("per XCD: waves, busy wave-ms, last end (ms)")
 for x in np.unique(xcc):
     m = xcc == x
     print("  xcd %d: %7d  %8.2f  %6.3f" % (x, m.sum(), dur[m].sum() / 1e3, end[m].max() / 1e5))
+hw = raw[:, 2]
+slot = (xcc.astype(np.int64) << 16) | (hw & 0x7fff)
+cu = (xcc.astype(np.int64) << 16) | (hw & 0x7f00)
+simd = (xcc.astype(np.int64) << 16) | (hw & 0x7f30)
+print("distinct wave slots seen %d, SIMDs %d, compute units %d" % (len(np.unique(slot)), len(np.unique(simd)), len(np.unique(cu))))
+u_simd, inv = np.unique(simd, return_inverse=True)
+slots_per_simd = np.array([len(np.unique(slot[inv == k])) for k in range(len(u_simd))])
+print("wave slots used per SIMD: min %d max %d mean %.2f; histogram %s" % (slots_per_simd.min(), slots_per_simd.max(), slots_per_simd.mean(), np.bincount(slots_per_simd).tolist()))
+tx = (w + 7) // 8
+order = np.argsort(-dur)[:24]
+print("longest waves: (tile x, tile y) life us, start ms")
+print("  " + "  ".join("(%d,%d) %.0f @%.2f" % (i % tx, i // tx, dur[i], start[i] / 1e5) for i in order))
+ty = (h + 7) // 8
+grid = dur.reshape(ty, tx)
+print("mean life by tile column block (16 blocks):", [int(grid[:, k * tx // 16:(k + 1) * tx // 16].mean()) for k in range(16)])
+print("centre columns %d..%d mean life: %s" % (tx // 2 - 3, tx // 2 + 2, [int(grid[:, c].mean()) for c in range(tx // 2 - 3, tx // 2 + 3)]))
