@@ -409,7 +409,7 @@ __global__ __launch_bounds__(RT_WBLOCK, BOUNCE ? RT_WAVES_PER_SIMD_BOUNCE : RT_W
   float* my_park = &parked[tid];
   WaveStack st = {0u, 0u, 0u, 0u};
   const int W = cam.width, H = cam.height;
-  // Pixel of a thread: wave w of the block owns the 8x8 tile (w & 1, w >> 1) of the block's 16x16 pixels.  The
+  // Pixel of a thread: wave w of the block owns the 8x8 tile (w % RT_WAVES_X, w / RT_WAVES_X) of the block's pixels.  The
   // coordinates are needed at the start, after the primary ray and at the end; they are derived again each time
   // from an opaque copy of the thread index, so that none of them occupies a register (or a spill slot) in between.
   struct Pixel { int col, lrow, row, orow; bool valid; };   // (derived per use, see below)

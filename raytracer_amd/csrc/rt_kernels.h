@@ -7,8 +7,8 @@
 #include "rt_internal.h"
 #include "rt_math.h"
 
-#define RT_BLOCK 256
-#define RT_TILE_W 16   // pixels per workgroup tile: four 8x8 wave tiles
+#define RT_BLOCK 256     // literal cross-check kernel (the wave kernel has its own, RT_WBLOCK)
+#define RT_TILE_W 16   // its pixels per workgroup: four 8x8 wave tiles; bands are whole multiples of RT_TILE_H rows
 #define RT_TILE_H 16
 
 // Device-resident scene, passed to kernels by value.
