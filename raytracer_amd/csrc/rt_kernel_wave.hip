@@ -135,7 +135,7 @@ __device__ __forceinline__ void trace_wave(const float4* __restrict__ nodes, int
       float4 na, nb;
       uint64_t acc_m, und_m;
       // conservative slab classification first; the exact test only where some lane is within rounding of a boundary
-      if (presorted) {
+      if (presorted || zpat != 0u) {
         // Siblings are scanned in a tight loop until one is accepted by some lane (or needs the exact test): about two
         // node tests in three end in "no lane", and those never leave this loop.
         // A record is consumed by six subtractions (plane - e) and two scalar copies (links); the request for the next
@@ -143,36 +143,62 @@ __device__ __forceinline__ void trace_wave(const float4* __restrict__ nodes, int
         // record occupied: nothing is copied from "next" to "current".  Whoever needs the planes again (the exact test,
         // rarely) reads the record once more.
         uint32_t c_cur = 0u, r_first = 0u, r_meta = 0u;
-        for (;;) {
-          c_cur = (uint32_t)__builtin_ctz(rem);
-          rem &= rem - 1u;
-          const float dx0 = nx_a.x - e.x, dx1 = nx_a.y - e.x, dy0 = nx_a.z - e.y, dy1 = nx_a.w - e.y, dz0 = nx_b.x - e.z, dz1 = nx_b.y - e.z;
-          r_first = uni(__float_as_uint(nx_b.z)); r_meta = uni(__float_as_uint(nx_b.w));
-          {
-            // next sibling ("child 8" after the last one is the first record of the next block or the pad record)
-            uint32_t off = (uint32_t)__builtin_ctz(rem | 0x100u) * 32u;   // byte offset of that record within the block
-            asm volatile("" : "+s"(off) : "v"(dx0), "v"(dx1), "v"(dy0), "v"(dy1), "v"(dz0), "v"(dz1), "s"(r_first), "s"(r_meta));
-            const cnode_ptr rp = (cnode_ptr)((const __attribute__((address_space(4))) char*)blk + off);
-            nx_a = rec(rp); nx_b = rec(rp + 1);
-          }
-          if (PATHS && r_meta != 0u) tl.w[1]++;
-          if (COUNT && ((mine_m >> lane) & 1ull)) tl.node++;   // w[1]: iterations the plain variant also makes
-          const float tx0 = dx0 * inv.x, tx1 = dx1 * inv.x, ty0 = dy0 * inv.y, ty1 = dy1 * inv.y, tz0 = dz0 * inv.z, tz1 = dz1 * inv.z;
-          const RtSlabHead hd = rt_node_slab_head(tx0, tx1, ty0, ty1, tz0, tz1, hit.t);
-          // Most children are missed by every ray of the wave, and by far: those are settled against the ray's largest
-          // possible margin, without working out the margin of this node.
-          acc_m = 0ull; und_m = 0ull;
-          if ((mine_m & ~__builtin_amdgcn_ballot_w64(hd.r < neg_eb)) != 0ull) {
-#ifdef RT_PATH_QUICK
-            tl.w[3]++;
-#endif
-            bool c_acc, c_rej;
-            rt_node_slab_tail(hd, tx0, tx1, ty0, ty1, tz0, tz1, hit.t, c_acc, c_rej);
-            acc_m = __builtin_amdgcn_ballot_w64(c_acc) & mine_m;
-            und_m = mine_m & ~(acc_m | __builtin_amdgcn_ballot_w64(c_rej));
-          }
-          if ((acc_m | und_m) != 0ull || rem == 0u) break;
+        // (RT_SCAN_LOOP stamps the loop out once per kind of node test: CLASSIFY turns the six differences into acc_m / und_m)
+#define RT_SCAN_LOOP(SIDE, ...)                                                                                                         \
+        for (;;) {                                                                                                                      \
+          c_cur = (uint32_t)__builtin_ctz(rem);                                                                                         \
+          rem &= rem - 1u;                                                                                                              \
+          const float dx0 = nx_a.x - e.x, dx1 = nx_a.y - e.x, dy0 = nx_a.z - e.y, dy1 = nx_a.w - e.y, dz0 = nx_b.x - e.z, dz1 = nx_b.y - e.z; \
+          SIDE;                                                                                                                         \
+          r_first = uni(__float_as_uint(nx_b.z)); r_meta = uni(__float_as_uint(nx_b.w));                                                \
+          {                                                                                                                             \
+            /* next sibling ("child 8" after the last one is the first record of the next block or the pad record) */                  \
+            uint32_t off = (uint32_t)__builtin_ctz(rem | 0x100u) * 32u;   /* byte offset of that record within the block */             \
+            asm volatile("" : "+s"(off) : "v"(dx0), "v"(dx1), "v"(dy0), "v"(dy1), "v"(dz0), "v"(dz1), "v"(side), "s"(r_first), "s"(r_meta)); \
+            const cnode_ptr rp = (cnode_ptr)((const __attribute__((address_space(4))) char*)blk + off);                                 \
+            nx_a = rec(rp); nx_b = rec(rp + 1);                                                                                         \
+          }                                                                                                                             \
+          if (PATHS && r_meta != 0u) tl.w[1]++;                                                                                         \
+          if (COUNT && ((mine_m >> lane) & 1ull)) tl.node++;   /* w[1]: iterations the plain variant also makes */                      \
+          acc_m = 0ull; und_m = 0ull;                                                                                                   \
+          __VA_ARGS__                                                                                                                   \
+          if ((acc_m | und_m) != 0ull || rem == 0u) break;                                                                              \
         }
+        // a direction component that is zero takes the node test written for that pattern (rt_node_slab_zero_d); the cube's
+        // side is taken from the record while it is there
+#define RT_CLASSIFY_ZERO(ZX, ZY, ZZ)                                                                                                    \
+          {                                                                                                                             \
+            const float dlo[3] = {dx0, dy0, dz0}, dhi[3] = {dx1, dy1, dz1};                                                             \
+            bool c_acc, c_rej;                                                                                                          \
+            rt_node_slab_zero_d<ZX, ZY, ZZ>(dlo, dhi, side, inv, hit.t, c_acc, c_rej);                                                  \
+            acc_m = __builtin_amdgcn_ballot_w64(c_acc) & mine_m;                                                                        \
+            und_m = mine_m & ~(acc_m | __builtin_amdgcn_ballot_w64(c_rej));                                                             \
+          }
+        if (presorted) {
+          RT_SCAN_LOOP(const float side = dx0, {
+            const float tx0 = dx0 * inv.x, tx1 = dx1 * inv.x, ty0 = dy0 * inv.y, ty1 = dy1 * inv.y, tz0 = dz0 * inv.z, tz1 = dz1 * inv.z;
+            const RtSlabHead hd = rt_node_slab_head(tx0, tx1, ty0, ty1, tz0, tz1, hit.t);
+            /* Most children are missed by every ray of the wave, and by far: those are settled against the ray's largest
+               possible margin, without working out the margin of this node. */
+            if ((mine_m & ~__builtin_amdgcn_ballot_w64(hd.r < neg_eb)) != 0ull) {
+              bool c_acc, c_rej;
+              rt_node_slab_tail(hd, tx0, tx1, ty0, ty1, tz0, tz1, hit.t, c_acc, c_rej);
+              acc_m = __builtin_amdgcn_ballot_w64(c_acc) & mine_m;
+              und_m = mine_m & ~(acc_m | __builtin_amdgcn_ballot_w64(c_rej));
+            }
+          })
+        } else {
+          switch (zpat) {
+            case 1u: RT_SCAN_LOOP(const float side = nx_a.y - nx_a.x, RT_CLASSIFY_ZERO(true, false, false)) break;
+            case 2u: RT_SCAN_LOOP(const float side = nx_a.y - nx_a.x, RT_CLASSIFY_ZERO(false, true, false)) break;
+            case 3u: RT_SCAN_LOOP(const float side = nx_a.y - nx_a.x, RT_CLASSIFY_ZERO(true, true, false)) break;
+            case 4u: RT_SCAN_LOOP(const float side = nx_a.y - nx_a.x, RT_CLASSIFY_ZERO(false, false, true)) break;
+            case 5u: RT_SCAN_LOOP(const float side = nx_a.y - nx_a.x, RT_CLASSIFY_ZERO(true, false, true)) break;
+            default: RT_SCAN_LOOP(const float side = nx_a.y - nx_a.x, RT_CLASSIFY_ZERO(false, true, true)) break;
+          }
+        }
+#undef RT_SCAN_LOOP
+#undef RT_CLASSIFY_ZERO
         na = float4{0.f, 0.f, 0.f, 0.f}; nb = float4{0.f, 0.f, 0.f, 0.f};
         if (und_m) { na = rec(blk + NS * c_cur); nb = rec(blk + NS * c_cur + 1); }   // the exact test wants the planes again
         nb.z = __uint_as_float(r_first); nb.w = __uint_as_float(r_meta);
@@ -185,18 +211,6 @@ __device__ __forceinline__ void trace_wave(const float4* __restrict__ nodes, int
         if (!any_zero) {
           bool c_acc, c_rej;
           rt_node_slab_fast(na.x, na.y, na.z, na.w, nb.x, nb.y, e, inv, hit.t, c_acc, c_rej);
-          acc_m = __builtin_amdgcn_ballot_w64(c_acc) & mine_m;
-          und_m = mine_m & ~(acc_m | __builtin_amdgcn_ballot_w64(c_rej));
-        } else if (zpat != 0u) {
-          bool c_acc = false, c_rej = false;
-          switch (zpat) {
-            case 1u: rt_node_slab_zero<true, false, false>(na.x, na.y, na.z, na.w, nb.x, nb.y, e, inv, hit.t, c_acc, c_rej); break;
-            case 2u: rt_node_slab_zero<false, true, false>(na.x, na.y, na.z, na.w, nb.x, nb.y, e, inv, hit.t, c_acc, c_rej); break;
-            case 3u: rt_node_slab_zero<true, true, false>(na.x, na.y, na.z, na.w, nb.x, nb.y, e, inv, hit.t, c_acc, c_rej); break;
-            case 4u: rt_node_slab_zero<false, false, true>(na.x, na.y, na.z, na.w, nb.x, nb.y, e, inv, hit.t, c_acc, c_rej); break;
-            case 5u: rt_node_slab_zero<true, false, true>(na.x, na.y, na.z, na.w, nb.x, nb.y, e, inv, hit.t, c_acc, c_rej); break;
-            default: rt_node_slab_zero<false, true, true>(na.x, na.y, na.z, na.w, nb.x, nb.y, e, inv, hit.t, c_acc, c_rej); break;
-          }
           acc_m = __builtin_amdgcn_ballot_w64(c_acc) & mine_m;
           und_m = mine_m & ~(acc_m | __builtin_amdgcn_ballot_w64(c_rej));
         } else {

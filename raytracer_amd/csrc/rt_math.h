@@ -433,8 +433,10 @@ RT_HD void rt_node_slab_zero_d(const float* dlo, const float* dhi, float side, c
   for (int k = 0; k < 3; k++) {
     if (Z[k]) {
       const float A = -dlo[k], B = dhi[k];
-      in_all = (int)in_all & (int)(fminf(A, B) > 0.f) & (int)(fmaxf(A, B) < side);
-      out_any = (int)out_any | ((int)(A < 0.f) & (int)(B > side)) | ((int)(B < 0.f) & (int)(A > side));
+      const float mn = fminf(A, B), mx = fmaxf(A, B);
+      in_all = (int)in_all & (int)(mn > 0.f) & (int)(mx < side);
+      // (A < 0 and B > side) or (B < 0 and A > side): with side > 0 the negative one is the smaller, the other the larger
+      out_any = (int)out_any | ((int)(mn < 0.f) & (int)(mx > side));
     } else {
       const float t0 = dlo[k] * iv[k], t1 = dhi[k] * iv[k];
       n[K] = fminf(t0, t1); f[K] = fmaxf(t0, t1); K++;
