@@ -169,10 +169,13 @@ __device__ __forceinline__ void trace_wave(const float4* __restrict__ nodes, int
 #define RT_CLASSIFY_ZERO(ZX, ZY, ZZ)                                                                                                    \
           {                                                                                                                             \
             const float dlo[3] = {dx0, dy0, dz0}, dhi[3] = {dx1, dy1, dz1};                                                             \
-            bool c_acc, c_rej;                                                                                                          \
-            rt_node_slab_zero_d<ZX, ZY, ZZ>(dlo, dhi, side, inv, hit.t, c_acc, c_rej);                                                  \
-            acc_m = __builtin_amdgcn_ballot_w64(c_acc) & mine_m;                                                                        \
-            und_m = mine_m & ~(acc_m | __builtin_amdgcn_ballot_w64(c_rej));                                                             \
+            /* most children lie beside every ray of the wave: settled without any slab arithmetic */                                  \
+            if ((mine_m & ~__builtin_amdgcn_ballot_w64(rt_node_zero_outside<ZX, ZY, ZZ>(dlo, dhi, side))) != 0ull) {                   \
+              bool c_acc, c_rej;                                                                                                        \
+              rt_node_slab_zero_d<ZX, ZY, ZZ>(dlo, dhi, side, inv, hit.t, c_acc, c_rej);                                                \
+              acc_m = __builtin_amdgcn_ballot_w64(c_acc) & mine_m;                                                                      \
+              und_m = mine_m & ~(acc_m | __builtin_amdgcn_ballot_w64(c_rej));                                                           \
+            }                                                                                                                           \
           }
         if (presorted) {
           RT_SCAN_LOOP(const float side = dx0, {

@@ -456,6 +456,19 @@ RT_HD void rt_node_slab_zero_d(const float* dlo, const float* dhi, float side, c
   rej = (rt_min3(span, tF, x) < -E) | out_any;
   acc = (fminf(a, tc) > E) & in_all & !rej;
 }
+// The part of that rejection which needs no slab arithmetic at all: the origin lies outside the cube's extent on a zero
+// axis (for a ray parallel to an axis: outside the cube's footprint).  Implies rej of rt_node_slab_zero_d.
+template <bool ZX, bool ZY, bool ZZ>
+RT_HD bool rt_node_zero_outside(const float* dlo, const float* dhi, float side) {
+  const bool Z[3] = {ZX, ZY, ZZ};
+  bool out_any = false;
+  for (int k = 0; k < 3; k++) {
+    if (!Z[k]) continue;
+    const float A = -dlo[k], B = dhi[k];
+    out_any = (int)out_any | ((int)(fminf(A, B) < 0.f) & (int)(fmaxf(A, B) > side));
+  }
+  return out_any;
+}
 template <bool ZX, bool ZY, bool ZZ>
 RT_HD void rt_node_slab_zero(float lox, float hix, float loy, float hiy, float loz, float hiz, const RtVec3& e, const RtVec3& inv,
                              float T, bool& acc, bool& rej) {

@@ -48,6 +48,20 @@ static bool check_node(const RtVec3& ini, const RtVec3& end, const RtVec3& e, co
         case 6: rt_node_slab_zero<false, true, true>(lo.x, hi.x, lo.y, hi.y, lo.z, hi.z, e, inv, T, za, zr); break;
       }
       n_zero_axis++;
+      {   // the footprint part of the rejection on its own may only fire where the whole form rejects
+        const float dlo[3] = {lo.x - e.x, lo.y - e.y, lo.z - e.z}, dhi[3] = {hi.x - e.x, hi.y - e.y, hi.z - e.z};
+        const float side = hi.x - lo.x;
+        bool o = false;
+        switch (zp) {
+          case 1: o = rt_node_zero_outside<true, false, false>(dlo, dhi, side); break;
+          case 2: o = rt_node_zero_outside<false, true, false>(dlo, dhi, side); break;
+          case 3: o = rt_node_zero_outside<true, true, false>(dlo, dhi, side); break;
+          case 4: o = rt_node_zero_outside<false, false, true>(dlo, dhi, side); break;
+          case 5: o = rt_node_zero_outside<true, false, true>(dlo, dhi, side); break;
+          case 6: o = rt_node_zero_outside<false, true, true>(dlo, dhi, side); break;
+        }
+        if (o && !zr) { if (n_bad < 10) printf("ZERO-AXIS OUTSIDE WITHOUT REJECTION pattern %d\n", zp); n_bad++; }
+      }
       if (za != (cls > 0) || zr != (cls < 0)) {
         if (n_bad < 10) printf("SLAB ZERO-PATTERN/GENERAL DIFFER pattern %d cls %d special %d %d\n", zp, cls, (int)za, (int)zr);
         n_bad++;
