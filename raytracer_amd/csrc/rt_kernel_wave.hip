@@ -102,8 +102,8 @@ __device__ __forceinline__ void trace_wave(const float4* __restrict__ nodes, int
     typedef const __attribute__((address_space(4))) f4* cnode_ptr;
     const cnode_ptr cnodes = (cnode_ptr)(uintptr_t)nodes;
     auto rec = [](cnode_ptr p) { const f4 v = *p; return float4{v.x, v.y, v.z, v.w}; };
-    uint32_t top_first = uni(__float_as_uint(nodes[1].z));   // the root is entered without a test (ray.cu:36-38)
-    uint32_t rem = COUNT ? 0xffu : (uni(__float_as_uint(nodes[1].w)) & 0xffu);
+    uint32_t top_first, rem;   // the root is entered without a test (ray.cu:36-38)
+    { const float4 root_b = rec(cnodes + 1); top_first = uni(__float_as_uint(root_b.z)); rem = COUNT ? 0xffu : (uni(__float_as_uint(root_b.w)) & 0xffu); }
     uint64_t top_mask = live;
     int sp = 0;
     // Node records reach the SGPRs through the scalar cache.  The record of the child that will be tested next is
@@ -250,7 +250,11 @@ __device__ __forceinline__ void trace_wave(const float4* __restrict__ nodes, int
         const uint32_t crem = COUNT ? 0xffu : (meta & 0xffu);
         if (crem == 0u) continue;
         if (rem != 0u) {
-          const bool slot = lane == sp;   // lane sp keeps entry sp
+          // lane sp keeps entry sp.  The lane number is counted afresh here (two instructions on an opaque mask) rather
+          // than kept in a register, or fetched from a spill slot, during the whole walk.
+          uint32_t ones = ~0u;
+          asm volatile("" : "+s"(ones));
+          const bool slot = (int)__builtin_amdgcn_mbcnt_hi(ones, __builtin_amdgcn_mbcnt_lo(ones, 0u)) == sp;
           st.first = slot ? top_first : st.first; st.cur = slot ? rem : st.cur;
           st.mask_lo = slot ? (uint32_t)top_mask : st.mask_lo; st.mask_hi = slot ? (uint32_t)(top_mask >> 32) : st.mask_hi;
           sp++;
@@ -411,21 +415,53 @@ __device__ __forceinline__ void unpark(ShadeState<BOUNCE>& s, const float* lds) 
 // BOUNCE: the scene has reflective or dielectric materials; COUNT: instrumented; QUEUES (with BOUNCE): bounce rays leave
 // through / arrive from the generation queues instead of living on the lane's stack (a variant of its own, so that
 // the stacked kernel does not carry the queue code in its registers).
+// The arguments of the kernel apart from the two arrays of the walk, as one block in the kernel-argument segment (behind
+// those two pointers, which are parameters of their own so that their loads are known to be read-only).  What the walk needs is taken
+// from it on entry.  Everything else (shading tables, output pointers, queues, frame geometry) is read where it is
+// used, through LATE(): a load from the argument segment behind an opaque copy of its address, which the compiler can
+// neither move in front of the walk nor keep in registers across it - the walk needs every scalar register it can get.
+struct RtWaveArgs {
+  RtCamera cam; RowMap rows;
+  const float4* tri_geom; const float4* tri_shade;
+  const RtSphere* spheres; const RtLight* lights; const RtMaterial* materials; const int32_t* mat_index;
+  const int32_t* mesh_mat_first; const int32_t* mesh_mat_count;
+  int n_spheres, n_lights, has_oct, n_wnodes;
+  uint8_t* rgb; int32_t* ids; float* ts; unsigned long long* counters_all; int tally;
+  RtQueues wf;
+};
+#define RT_WAVE_ARGS_OFFSET 16   // two pointers in front of the block
+static_assert(alignof(RtWaveArgs) == 8, "the block follows the two pointers without padding");
+typedef const __attribute__((address_space(4))) char* rt_kernarg_ptr;
+__device__ __forceinline__ rt_kernarg_ptr late_args() {
+  rt_kernarg_ptr p = (rt_kernarg_ptr)__builtin_amdgcn_kernarg_segment_ptr() + RT_WAVE_ARGS_OFFSET;
+  asm volatile("" : "+s"(p));
+  return p;
+}
+#define LATE(field) (*(const __attribute__((address_space(4))) decltype(RtWaveArgs::field)*)(late_args() + offsetof(RtWaveArgs, field)))
+// (the same for a whole member struct, word by word)
+template <typename T>
+__device__ __forceinline__ T late_struct(size_t offset) {
+  static_assert(sizeof(T) % 4 == 0, "whole words");
+  const __attribute__((address_space(4))) uint32_t* src = (const __attribute__((address_space(4))) uint32_t*)(late_args() + offset);
+  uint32_t w[sizeof(T) / 4];
+  for (size_t i = 0; i < sizeof(T) / 4; i++) w[i] = src[i];
+  T v;
+  __builtin_memcpy(&v, w, sizeof(T));
+  return v;
+}
+#define LATE_STRUCT(field) late_struct<decltype(RtWaveArgs::field)>(offsetof(RtWaveArgs, field))
+
 template <bool BOUNCE, bool COUNT, bool QUEUES>
 __global__ __launch_bounds__(RT_WBLOCK, BOUNCE ? RT_WAVES_PER_SIMD_BOUNCE : RT_WAVES_PER_SIMD) void render_wave(
-    const RtCamera cam, const RowMap rows, const float4* __restrict__ nodes, const float4* __restrict__ tri_leaf,
-    const float4* __restrict__ tri_geom, const float4* __restrict__ tri_shade, const RtSphere* __restrict__ spheres,
-    const RtLight* __restrict__ lights, const RtMaterial* __restrict__ materials, const int32_t* __restrict__ mat_index,
-    const int32_t* __restrict__ mesh_mat_first, const int32_t* __restrict__ mesh_mat_count, int n_spheres, int n_lights, int has_oct, int n_wnodes,
-    uint8_t* __restrict__ rgb, int32_t* __restrict__ ids, float* __restrict__ ts, unsigned long long* __restrict__ counters_all, int tally,
-    const RtQueues wf) {
-  unsigned long long* const counters = counters_all + ((blockIdx.x + blockIdx.y) & (RT_COUNTER_COPIES - 1)) * RT_COUNTER_STRIDE;
+    const float4* __restrict__ nodes, const float4* __restrict__ tri_leaf, const RtWaveArgs A) {
+  const RtSphere* __restrict__ spheres = A.spheres;
+  const int n_spheres = A.n_spheres, has_oct = A.has_oct, n_wnodes = A.n_wnodes;
+  auto counters_ptr = [&]() { return LATE(counters_all) + ((blockIdx.x + blockIdx.y) & (RT_COUNTER_COPIES - 1)) * RT_COUNTER_STRIDE; };
   __shared__ float parked[ShadeState<BOUNCE>::WORDS * RT_WBLOCK];
   __shared__ uint32_t pack[RT_WBLOCK / 64][48];
   const int tid = threadIdx.x, lane = tid & 63;
   float* my_park = &parked[tid];
   WaveStack st = {0u, 0u, 0u, 0u};
-  const int W = cam.width, H = cam.height;
   // Pixel of a thread: wave w of the block owns the 8x8 tile (w % RT_WAVES_X, w / RT_WAVES_X) of the block's pixels.  The
   // coordinates are needed at the start, after the primary ray and at the end; they are derived again each time
   // from an opaque copy of the thread index, so that none of them occupies a register (or a spill slot) in between.
@@ -433,6 +469,8 @@ __global__ __launch_bounds__(RT_WBLOCK, BOUNCE ? RT_WAVES_PER_SIMD_BOUNCE : RT_W
   auto pixel_of = [&](int t) {
     asm volatile("" : "+v"(t));
     const int w = t >> 6, l = t & 63;
+    const RowMap rows = LATE_STRUCT(rows);
+    const int W = LATE(cam).width, H = LATE(cam).height;
     Pixel p;
     if (rows.small) {
       p.col = blockIdx.x * (RT_WTILE_W / 2) + (w % RT_WAVES_X) * 4 + (l & 3);
@@ -447,7 +485,7 @@ __global__ __launch_bounds__(RT_WBLOCK, BOUNCE ? RT_WAVES_PER_SIMD_BOUNCE : RT_W
     return p;
   };
   Tally tl = {0, 0, 0, 0, 0, 0, 0, {0, 0, 0, 0, 0, 0, 0, 0}};
-  const RtCamera& c = cam;
+  const RtCamera& c = A.cam;   // (entry only: primary ray set-up)
 #ifdef RT_WAVE_TIMES
   // Diagnostic build: every wave leaves (start, end) of its life on the 100 MHz clock and where it ran in the `t`
   // output, four words per wave in launch order (tools/wave_times.py); the per-pixel t is not written then.
@@ -455,18 +493,17 @@ __global__ __launch_bounds__(RT_WBLOCK, BOUNCE ? RT_WAVES_PER_SIMD_BOUNCE : RT_W
 #endif
 
   // view handed to the helpers of rt_kernels.h
-  RtDeviceView S;
-  S.tri_geom = tri_geom; S.tri_shade = tri_shade; S.spheres = spheres;
 
   // ---- registers that live across the traversal: the ray being traced and a few flags -----------------
   RtVec3 tr_e, tr_d;        // ray being traced
   float tr_stop = -1.f;     // >= 0: shadow ray, length to the light
   int phase;
   const bool wavefront = BOUNCE && QUEUES;                    // bounce rays leave through the queue
-  const bool queued = BOUNCE && QUEUES && wf.in != nullptr;   // this launch renders a queue of bounce rays, one per lane
+  const bool queued = BOUNCE && QUEUES && A.wf.in != nullptr;   // this launch renders a queue of bounce rays, one per lane
   if (!queued) {
     const Pixel px0 = pixel_of(tid);
     phase = px0.valid ? PH_CLOSEST : PH_DONE;
+    const int W = A.cam.width, H = A.cam.height;
     const int i = px0.col, j = H - 1 - px0.row;   // camera.cu:94,118: j counts from the bottom
     // camera.cu:96-99; (i+0.5) is a double, so product and sum are double before the store to float
     const float ic = (float)((double)c.left + (double)((c.right - c.left) / (float)(unsigned short)W) * ((double)i + 0.5));
@@ -491,6 +528,7 @@ __global__ __launch_bounds__(RT_WBLOCK, BOUNCE ? RT_WAVES_PER_SIMD_BOUNCE : RT_W
   // finished by the term list instead of by this lane
   uint32_t q_pixel = 0u; unsigned long long q_path = 0ull; int q_pushes = 0; bool q_pending = false;
   if (queued) {
+    const RtQueues& wf = A.wf;
     const uint32_t per_wave = (uint32_t)wf.rays_per_wave;
     const uint32_t gid = (blockIdx.x * (RT_WBLOCK / 64) + (tid >> 6)) * per_wave + lane;
     phase = PH_DONE; tr_e = {0.f, 0.f, 0.f}; tr_d = {0.f, 0.f, 1.f};
@@ -506,7 +544,8 @@ __global__ __launch_bounds__(RT_WBLOCK, BOUNCE ? RT_WAVES_PER_SIMD_BOUNCE : RT_W
   // A ray pushed by the hit being shaded (ray.cuh:22-27): onto the lane's stack, or into the queue of the next generation.
   auto push_ray = [&](const RtVec3& eye, const RtVec3& dir, const RtVec3& att, int nlevel) {
     if (BOUNCE && wavefront) {
-      if (!queued && q_pushes == 0) { const Pixel px = pixel_of(tid); q_pixel = (uint32_t)((size_t)px.orow * W + px.col); }
+      const RtQueues wf = LATE_STRUCT(wf);
+      if (!queued && q_pushes == 0) { const Pixel px = pixel_of(tid); q_pixel = (uint32_t)((size_t)px.orow * LATE(cam).width + px.col); }
       // one slot per pushing lane: the lanes active here count themselves and the first of them reserves the run
       const uint64_t m = __builtin_amdgcn_ballot_w64(true);
       const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
@@ -530,7 +569,7 @@ __global__ __launch_bounds__(RT_WBLOCK, BOUNCE ? RT_WAVES_PER_SIMD_BOUNCE : RT_W
         r.eye = eye; r.dir = dir; r.att = att;
         r.level[0] = sh.level0; r.level[1] = sh.level1; r.level[2] = sh.level2;
         r.nlevel = nlevel; r.depth = sh.depth + 1;
-      } else atomicAdd(&counters[C_UB_STACK], 1ull);
+      } else atomicAdd(&counters_ptr()[C_UB_STACK], 1ull);
     }
   };
 
@@ -551,9 +590,10 @@ __global__ __launch_bounds__(RT_WBLOCK, BOUNCE ? RT_WAVES_PER_SIMD_BOUNCE : RT_W
     if (phase == PH_CLOSEST) {
       if (primary) {
         primary = false;
+        int32_t* const ids = LATE(ids); float* const ts = LATE(ts);
         if (ids || ts) {
           const Pixel px = pixel_of(tid);
-          const size_t p = (size_t)px.orow * W + px.col;
+          const size_t p = (size_t)px.orow * LATE(cam).width + px.col;
           if (ids) ids[p] = h.prim;
 #ifndef RT_WAVE_TIMES
           if (ts) ts[p] = h.t;
@@ -563,13 +603,15 @@ __global__ __launch_bounds__(RT_WBLOCK, BOUNCE ? RT_WAVES_PER_SIMD_BOUNCE : RT_W
       sh.colr = {0.f, 0.f, 0.f};
       sh.mi = 0; sh.li = 0; sh.vis_known = 0; sh.vis_occluded = 0; sh.hit_t = h.t; sh.view = tr_d;
       if (h.prim == -1) {
-        sh.colr = {c.bg[0], c.bg[1], c.bg[2]};   // ray.cu:86
+        sh.colr = {LATE(cam).bg[0], LATE(cam).bg[1], LATE(cam).bg[2]};   // ray.cu:86
         sh.mcount = 0;
       } else {
+        RtDeviceView S;   // view handed to the helpers of rt_kernels.h
+        S.tri_geom = LATE(tri_geom); S.tri_shade = LATE(tri_shade); S.spheres = spheres;
         surface(S, tr_e, tr_d, h, sh.P, sh.N);
         if (h.prim >= 0) {
-          const int32_t mesh = (int32_t)__float_as_uint(tri_geom[3 * h.prim + 2].y);
-          sh.mfirst = mesh_mat_first[mesh]; sh.mcount = mesh_mat_count[mesh];
+          const int32_t mesh = (int32_t)__float_as_uint(S.tri_geom[3 * h.prim + 2].y);
+          sh.mfirst = LATE(mesh_mat_first)[mesh]; sh.mcount = LATE(mesh_mat_count)[mesh];
         } else { sh.mfirst = spheres[-2 - h.prim].mat_first; sh.mcount = spheres[-2 - h.prim].mat_count; }
       }
     } else if (phase == PH_SHADOW) {
@@ -582,7 +624,8 @@ __global__ __launch_bounds__(RT_WBLOCK, BOUNCE ? RT_WAVES_PER_SIMD_BOUNCE : RT_W
         if (sh.mi >= sh.mcount) {   // every material of the hit handled: camera.cu:110-111, then next ray of the pixel
           if (BOUNCE && wavefront && (queued || q_pushes > 0)) {
             // the ray's contribution goes to the term list; the pixel is summed up from there, in the reference's order
-            if (!queued && q_pushes == 0) { const Pixel px = pixel_of(tid); q_pixel = (uint32_t)((size_t)px.orow * W + px.col); }
+            const RtQueues wf = LATE_STRUCT(wf);
+            if (!queued && q_pushes == 0) { const Pixel px = pixel_of(tid); q_pixel = (uint32_t)((size_t)px.orow * LATE(cam).width + px.col); }
             const uint64_t m = __builtin_amdgcn_ballot_w64(true);
             const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
             uint32_t base = 0u;
@@ -609,12 +652,12 @@ __global__ __launch_bounds__(RT_WBLOCK, BOUNCE ? RT_WAVES_PER_SIMD_BOUNCE : RT_W
           } else phase = PH_DONE;
           break;
         }
-        const RtMaterial M = materials[mat_index[sh.mfirst + sh.mi]];
+        const RtMaterial M = LATE(materials)[LATE(mat_index)[sh.mfirst + sh.mi]];
         const RtVec3 P = sh.P, N = sh.N;
         if (M.type == RT_LAMBERT || M.type == RT_PHONG) {   // material.cu:15-24, lights.cu:260-367
           const int li = sh.li;
-          if (li >= n_lights) { sh.mi++; sh.li = 0; continue; }
-          const RtLight L = lights[li];
+          if (li >= LATE(n_lights)) { sh.mi++; sh.li = 0; continue; }
+          const RtLight L = LATE(lights)[li];
           if (L.type == RT_AMBIENT) {
             if (M.type == RT_LAMBERT) {
               sh.colr.x = sh.colr.x + M.col[0] * L.col[0]; sh.colr.y = sh.colr.y + M.col[1] * L.col[1]; sh.colr.z = sh.colr.z + M.col[2] * L.col[2];
@@ -626,7 +669,7 @@ __global__ __launch_bounds__(RT_WBLOCK, BOUNCE ? RT_WAVES_PER_SIMD_BOUNCE : RT_W
           else l = rt_normalized({L.pos[0] - P.x, L.pos[1] - P.y, L.pos[2] - P.z});
           const RtVec3 sP = {P.x + l.x * RT_EPS, P.y + l.y * RT_EPS, P.z + l.z * RT_EPS};
           if (L.type != RT_DIRECTIONAL) ldist = rt_len({L.pos[0] - sP.x, L.pos[1] - sP.y, L.pos[2] - sP.z});
-          if (c.shadows) {   // ray.cu:56-72
+          if (LATE(cam).shadows) {   // ray.cu:56-72
             bool occluded;
             if (verdict >= 0) {   // the trace requested by this very step has come back
               occluded = verdict != 0; verdict = -1;
@@ -656,7 +699,7 @@ __global__ __launch_bounds__(RT_WBLOCK, BOUNCE ? RT_WAVES_PER_SIMD_BOUNCE : RT_W
           sh.colr.z = sh.colr.z + (M.col[2] * L.col[2]) * w;
           sh.li++;
         } else {
-          if (BOUNCE && sh.depth < c.max_depth) {
+          if (BOUNCE && sh.depth < LATE(cam).max_depth) {
             const RtVec3 vd = sh.view;
             const float s2 = 2 * rt_dot(vd, N);
             const RtVec3 rl = rt_normalized({vd.x - N.x * s2, vd.y - N.y * s2, vd.z - N.z * s2});
@@ -687,11 +730,11 @@ __global__ __launch_bounds__(RT_WBLOCK, BOUNCE ? RT_WAVES_PER_SIMD_BOUNCE : RT_W
                 int nl;
                 if (entering) {
                   nl = sh.nlevel + 1;
-                  if (nl > 2) { nl = 2; atomicAdd(&counters[C_UB_OVER], 1ull); }
+                  if (nl > 2) { nl = 2; atomicAdd(&counters_ptr()[C_UB_OVER], 1ull); }
                   sh.set_level(nl, M.param);
                 } else {
                   nl = sh.nlevel - 1;
-                  if (nl < 0) { nl = 0; atomicAdd(&counters[C_UB_LEAVE], 1ull); }
+                  if (nl < 0) { nl = 0; atomicAdd(&counters_ptr()[C_UB_LEAVE], 1ull); }
                 }
                 push_ray({P.x + rf.x * RT_EPS, P.y + rf.y * RT_EPS, P.z + rf.z * RT_EPS}, rf, {attf[0], attf[1], attf[2]}, nl);
                 for (int k = 0; k < 3; k++) attl[k] = attl[k] * fresnel;
@@ -712,6 +755,9 @@ __global__ __launch_bounds__(RT_WBLOCK, BOUNCE ? RT_WAVES_PER_SIMD_BOUNCE : RT_W
   if (!queued) {
     const uint8_t q[3] = {rt_quantise(sh.color.x), rt_quantise(sh.color.y), rt_quantise(sh.color.z)};
     const Pixel pxe = pixel_of(tid);
+    const RowMap rows = LATE_STRUCT(rows);
+    const int W = LATE(cam).width, H = LATE(cam).height;
+    uint8_t* const rgb = LATE(rgb);
     int wave = tid; asm volatile("" : "+v"(wave)); wave >>= 6;
     if (pxe.valid) tl.rays++;   // the primary ray
     const int col0 = pxe.col & ~7, lrow0 = pxe.lrow & ~7;   // tile origin (wave-uniform)
@@ -735,6 +781,7 @@ __global__ __launch_bounds__(RT_WBLOCK, BOUNCE ? RT_WAVES_PER_SIMD_BOUNCE : RT_W
   }
   (void)q_pending;
 #ifdef RT_WAVE_TIMES
+  float* const ts = LATE(ts);
   if (ts && !queued && lane == 0) {
     const unsigned long long wt_end = __builtin_amdgcn_s_memrealtime();
     const uint32_t hw = __builtin_amdgcn_s_getreg((31 << 11) | (0 << 6) | 4), xcc = __builtin_amdgcn_s_getreg((31 << 11) | (0 << 6) | 20);
@@ -744,7 +791,8 @@ __global__ __launch_bounds__(RT_WBLOCK, BOUNCE ? RT_WAVES_PER_SIMD_BOUNCE : RT_W
 #endif
 
   // work counters: wave reduction, one atomic per wave and counter
-  if (!tally) return;   // nobody asked for statistics
+  if (!LATE(tally)) return;   // nobody asked for statistics
+  unsigned long long* const counters = counters_ptr();
   const uint32_t vals[7] = {tl.rays, tl.shadow, tl.node, tl.leaf, tl.tri, tl.sph, tl.traced};
   const int slot[7] = {C_RAYS, C_SHADOW, C_NODE, C_LEAF, C_TRI, C_SPH, C_TRACED};
   for (int k = 0; k < 7; k++) {
@@ -766,10 +814,13 @@ void rt_launch_wave_kernel(const RtDeviceView& V, const RowMap& rows, bool bounc
     const uint32_t per_block = (RT_WBLOCK / 64) * (uint32_t)wf.rays_per_wave;
     grid = dim3((wf.n_in + per_block - 1) / per_block, 1); bounce = true;
   }
-#define LAUNCH(B, C, Q)                                                                                                          \
-  hipLaunchKernelGGL((render_wave<B, C, Q>), grid, block, 0, stream, V.cam, rows, V.wnodes, V.tri_leaf, V.tri_geom, V.tri_shade,  \
-                     V.spheres, V.lights, V.materials, V.mat_index, V.mesh_mat_first, V.mesh_mat_count, V.n_spheres, V.n_lights, \
-                     V.has_oct, V.n_wnodes, rgb, ids, ts, counters, tally ? 1 : 0, wf)
+  RtWaveArgs A;
+  A.cam = V.cam; A.rows = rows; A.tri_geom = V.tri_geom; A.tri_shade = V.tri_shade;
+  A.spheres = V.spheres; A.lights = V.lights; A.materials = V.materials; A.mat_index = V.mat_index;
+  A.mesh_mat_first = V.mesh_mat_first; A.mesh_mat_count = V.mesh_mat_count;
+  A.n_spheres = V.n_spheres; A.n_lights = V.n_lights; A.has_oct = V.has_oct; A.n_wnodes = V.n_wnodes;
+  A.rgb = rgb; A.ids = ids; A.ts = ts; A.counters_all = counters; A.tally = tally ? 1 : 0; A.wf = wf;
+#define LAUNCH(B, C, Q) hipLaunchKernelGGL((render_wave<B, C, Q>), grid, block, 0, stream, V.wnodes, V.tri_leaf, A)
   if (wf.enabled) { if (count) LAUNCH(true, true, true); else LAUNCH(true, false, true); }
   else if (bounce && count) LAUNCH(true, true, false);
   else if (bounce) LAUNCH(true, false, false);
