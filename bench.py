@@ -123,25 +123,40 @@ def main():
     scene = rt.Scene(args.scene, W, H, args.depth, base_dir=base_dir)
     info = scene.info()
     ds = rt.DeviceScene(scene, device=local_rank)
-    nb_max = ds.band_count(BAND_ROWS, 0, world)            # rank 0 owns the most bands
-    dist_on = world > 1 or os.environ.get("RT_BENCH_FORCE_DIST") == "1"   # the latter: rehearse the exchange on one GPU
+    # Rehearsals on one GPU: RT_BENCH_FORCE_DIST=1 runs the exchange with a world of one; RT_BENCH_SHARE_OF=N renders only
+    # the bands rank 0 of N would own (what one GPU of N does per frame).
+    share_of = int(os.environ.get("RT_BENCH_SHARE_OF", "0")) if world == 1 else 0
+    part_rank, part_world = (0, share_of) if share_of > 1 else (rank, world)
+    nb_max = ds.band_count(BAND_ROWS, 0, part_world)       # rank 0 owns the most bands
+    dist_on = world > 1 or os.environ.get("RT_BENCH_FORCE_DIST") == "1" or share_of > 1
+    if dist_on and world == 1:   # a rehearsal in a single process: it is its own rendezvous
+        for key, val in (("RANK", "0"), ("WORLD_SIZE", "1"), ("MASTER_ADDR", "127.0.0.1"), ("MASTER_PORT", "29533")):
+            os.environ.setdefault(key, val)
     if dist_on and not dist.is_initialized():
         dist.init_process_group("nccl", device_id=dev)
     # Two frame tiles per rank: the gather of frame k runs on the collective's stream while frame k+1 is rendered.
     local = [torch.zeros((nb_max * BAND_ROWS, W, 3), dtype=torch.uint8, device=dev) for _ in range(2 if dist_on else 1)]
     gathered = [[torch.zeros_like(local[0]) for _ in range(world)] for _ in local] if (dist_on and rank == 0) else None
     pending = [None, None]
-    stream = torch.cuda.current_stream()
+    # With several GPUs a rank's share of a frame is short, and it ends with the few long waves of its silhouette tiles
+    # while most of the chip idles.  So frames are pipelined two deep there: frame k+1 is rendered on a second stream
+    # into the second tile while frame k finishes and is gathered.  (Scenes whose bounce rays go through the scene's
+    # queue buffers render on one stream: those buffers exist once.)  One GPU: one stream, launches back to back.
+    two_deep = dist_on and not info.get("has_bounce_materials", 0) and os.environ.get("RT_BENCH_ONE_STREAM") != "1"
+    streams = [torch.cuda.current_stream()] + ([torch.cuda.Stream(device=dev)] if two_deep else [])
+    stream = streams[0]
 
     def step(k, flags=0, want_stats=False):
         b = k % len(local)
-        if pending[b] is not None:
-            pending[b].wait()          # the render stream waits for the gather that last read this tile
-            pending[b] = None
-        st = ds.render_bands_into(local[b].data_ptr(), BAND_ROWS, rank, world, stream=stream.cuda_stream, flags=flags,
-                                  want_stats=want_stats)
-        if dist_on:
-            pending[b] = dist.gather(local[b], gathered[b] if rank == 0 else None, dst=0, async_op=True)
+        sk = streams[b % len(streams)]
+        with torch.cuda.stream(sk):
+            if pending[b] is not None:
+                pending[b].wait()          # the render stream waits for the gather that last read this tile
+                pending[b] = None
+            st = ds.render_bands_into(local[b].data_ptr(), BAND_ROWS, part_rank, part_world, stream=sk.cuda_stream, flags=flags,
+                                      want_stats=want_stats)
+            if dist_on:
+                pending[b] = dist.gather(local[b], gathered[b] if rank == 0 else None, dst=0, async_op=True)
         return st
 
     def drain():
@@ -169,14 +184,16 @@ def main():
     t0 = time.perf_counter()
     for k in range(args.steps):
         b = k % len(local)
-        if pending[b] is not None:
-            pending[b].wait()
-            pending[b] = None
-        ev[k][0].record(stream)
-        ds.render_bands_into(local[b].data_ptr(), BAND_ROWS, rank, world, stream=stream.cuda_stream)
-        ev[k][1].record(stream)
-        if dist_on:
-            pending[b] = dist.gather(local[b], gathered[b] if rank == 0 else None, dst=0, async_op=True)
+        sk = streams[b % len(streams)]
+        with torch.cuda.stream(sk):
+            if pending[b] is not None:
+                pending[b].wait()
+                pending[b] = None
+            ev[k][0].record(sk)
+            ds.render_bands_into(local[b].data_ptr(), BAND_ROWS, part_rank, part_world, stream=sk.cuda_stream)
+            ev[k][1].record(sk)
+            if dist_on:
+                pending[b] = dist.gather(local[b], gathered[b] if rank == 0 else None, dst=0, async_op=True)
     drain()
     torch.cuda.synchronize()
     if dist_on:
@@ -205,7 +222,7 @@ def main():
         if ref is None and world == 1:
             # no recorded reference counts for this workload: take them from the instrumented kernel variant, whose
             # counts the parity tests hold identical to the oracle's (one extra launch, outside the timed region)
-            sc = ds.render_bands_into(local[0].data_ptr(), BAND_ROWS, rank, world, stream=stream.cuda_stream,
+            sc = ds.render_bands_into(local[0].data_ptr(), BAND_ROWS, part_rank, part_world, stream=stream.cuda_stream,
                                       flags=rt.RT_RENDER_COUNT_TESTS, want_stats=True)
             ref = {"rays": sc["rays"], "node_tests": sc["node_tests"], "tri_tests": sc["tri_tests"], "sphere_tests": sc["sphere_tests"]}
             counts_from = "instrumented kernel variant"
@@ -213,17 +230,20 @@ def main():
         if ref and ref["rays"] == rays_total:
             flop = ref["node_tests"] * F_NODE + ref["tri_tests"] * F_TRI + ref["sphere_tests"] * F_SPH + ref["rays"] * F_SHADE
             byts = ref["node_tests"] * B_NODE + ref["tri_tests"] * B_TRI + ref["rays"] * B_RAY
-            ach = flop / world / (kernel_ms * 1e-3) / 1e12     # per launch: this rank's share of the frame
+            # per launch: this rank's share of the frame over the launch's own duration; with frames pipelined two deep
+            # two launches share the GPU and their durations overlap, so the rate is taken over the time per frame then
+            t_ms = ms_per_step if two_deep else kernel_ms
+            ach = flop / world / (t_ms * 1e-3) / 1e12
             # The path is neither a dense contraction nor memory-bound: the roof that binds is FP32 vector issue.  The HBM
             # view is reported beside it (hbm_*): measured bytes per launch over the same kernel time, against 8 TB/s.
             roofline = {"bound": "valu_fp32", "achieved": ach, "peak": PEAK_FP32_TFLOPS, "unit": "TFLOP/s",
                         "frac": ach / PEAK_FP32_TFLOPS,
                         "traffic": (measured_traffic(rt.version()) if (world == 1 and W == 3840 and H == 2160 and
                                                                              args.scene.endswith("meshDragon.json")) else None),
-                        "kernel": "render_wave", "kernel_ms": kernel_ms, "test_counts_from": counts_from, "flop_per_ray": flop / ref["rays"],
-                        "algorithmic_GBps": byts / world / (kernel_ms * 1e-3) / 1e9, "hbm_peak_GBps": PEAK_HBM_GBS}
+                        "kernel": "render_wave", "kernel_ms": kernel_ms, "launches_overlap": bool(two_deep), "test_counts_from": counts_from, "flop_per_ray": flop / ref["rays"],
+                        "algorithmic_GBps": byts / world / (t_ms * 1e-3) / 1e9, "hbm_peak_GBps": PEAK_HBM_GBS}
         if roofline and roofline.get("traffic"):
-            roofline["hbm_achieved_GBps"] = roofline["traffic"] / (kernel_ms * 1e-3) / 1e9
+            roofline["hbm_achieved_GBps"] = roofline["traffic"] / ((ms_per_step if two_deep else kernel_ms) * 1e-3) / 1e9
             roofline["hbm_frac"] = roofline["hbm_achieved_GBps"] / PEAK_HBM_GBS
         out = {
             "metric": "Mrays/s at %dx%d %s" % (W, H, os.path.splitext(os.path.basename(args.scene))[0]), "value": mrays, "unit": "Mrays/s", "n_gpus": world,
@@ -233,7 +253,10 @@ def main():
                      "the reference's own scene and mesh files (deterministic, no RNG anywhere in the path)"),
             "config": {"workload": "%s %dx%d depth %d" % (os.path.join("scenes", os.path.basename(args.scene)), W, H, args.depth), "rays_per_frame": rays_total,
                        "shadow_rays_per_frame": shadow_total, "triangles": info["n_triangles"], "octree_nodes": info["n_nodes"],
-                       "partition": "%d-row bands round-robin over %d GPU(s), one RCCL gather per frame overlapped with the next frame's render" % (BAND_ROWS, world),
+                       "partition": ("one GPU renders the whole frame, no exchange" if not dist_on else
+                                     "%d-row bands round-robin over %d GPU(s), one RCCL gather per frame%s" % (
+                                         BAND_ROWS, world, ", frames pipelined two deep (the render of frame k+1 overlaps the end and the gather of frame k)"
+                                         if two_deep else " overlapped with the next frame's render")),
                        "library": rt.version()},
             "roofline": roofline,
         }
