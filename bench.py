@@ -140,11 +140,12 @@ def main():
     pending = [None, None]
     # With several GPUs a rank's share of a frame is short, and it ends with the few long waves of its silhouette tiles
     # while most of the chip idles.  So frames are pipelined two deep there: frame k+1 is rendered on a second stream
-    # into the second tile while frame k finishes and is gathered.  (Scenes whose bounce rays go through the scene's
-    # queue buffers render on one stream: those buffers exist once.)  One GPU: one stream, launches back to back.
-    two_deep = dist_on and not info.get("has_bounce_materials", 0) and os.environ.get("RT_BENCH_ONE_STREAM") != "1"
+    # into the second tile while frame k finishes and is gathered.  One GPU: one stream, launches back to back.
+    two_deep = dist_on and os.environ.get("RT_BENCH_ONE_STREAM") != "1"
     streams = [torch.cuda.current_stream()] + ([torch.cuda.Stream(device=dev)] if two_deep else [])
     stream = streams[0]
+    # one uploaded scene per stream: renders of one rt_dscene must not overlap (it owns one set of counters and queues)
+    scenes = [ds] + ([rt.DeviceScene(scene, device=local_rank)] if two_deep else [])
 
     def step(k, flags=0, want_stats=False):
         b = k % len(local)
@@ -153,8 +154,8 @@ def main():
             if pending[b] is not None:
                 pending[b].wait()          # the render stream waits for the gather that last read this tile
                 pending[b] = None
-            st = ds.render_bands_into(local[b].data_ptr(), BAND_ROWS, part_rank, part_world, stream=sk.cuda_stream, flags=flags,
-                                      want_stats=want_stats)
+            st = scenes[b % len(scenes)].render_bands_into(local[b].data_ptr(), BAND_ROWS, part_rank, part_world, stream=sk.cuda_stream,
+                                                           flags=flags, want_stats=want_stats)
             if dist_on:
                 pending[b] = dist.gather(local[b], gathered[b] if rank == 0 else None, dst=0, async_op=True)
         return st
@@ -190,7 +191,7 @@ def main():
                 pending[b].wait()
                 pending[b] = None
             ev[k][0].record(sk)
-            ds.render_bands_into(local[b].data_ptr(), BAND_ROWS, part_rank, part_world, stream=sk.cuda_stream)
+            scenes[b % len(scenes)].render_bands_into(local[b].data_ptr(), BAND_ROWS, part_rank, part_world, stream=sk.cuda_stream)
             ev[k][1].record(sk)
             if dist_on:
                 pending[b] = dist.gather(local[b], gathered[b] if rank == 0 else None, dst=0, async_op=True)
