@@ -437,7 +437,8 @@ __device__ __forceinline__ rt_kernarg_ptr late_args() {
   asm volatile("" : "+s"(p));
   return p;
 }
-#define LATE(field) (*(const __attribute__((address_space(4))) decltype(RtWaveArgs::field)*)(late_args() + offsetof(RtWaveArgs, field)))
+#define LATE_AT(ka, field) (*(const __attribute__((address_space(4))) decltype(RtWaveArgs::field)*)((ka) + offsetof(RtWaveArgs, field)))
+#define LATE(field) LATE_AT(late_args(), field)
 // (the same for a whole member struct, word by word)
 template <typename T>
 __device__ __forceinline__ T late_struct(size_t offset) {
@@ -587,10 +588,11 @@ __global__ __launch_bounds__(RT_WBLOCK, BOUNCE ? RT_WAVES_PER_SIMD_BOUNCE : RT_W
       asm volatile("" ::: "memory");
       unpark<BOUNCE>(sh, my_park);
     }
+    const rt_kernarg_ptr ka = late_args();   // one opaque copy for the whole shading phase: its loads go out together
     if (phase == PH_CLOSEST) {
       if (primary) {
         primary = false;
-        int32_t* const ids = LATE(ids); float* const ts = LATE(ts);
+        int32_t* const ids = LATE_AT(ka, ids); float* const ts = LATE_AT(ka, ts);
         if (ids || ts) {
           const Pixel px = pixel_of(tid);
           const size_t p = (size_t)px.orow * LATE(cam).width + px.col;
@@ -603,15 +605,15 @@ __global__ __launch_bounds__(RT_WBLOCK, BOUNCE ? RT_WAVES_PER_SIMD_BOUNCE : RT_W
       sh.colr = {0.f, 0.f, 0.f};
       sh.mi = 0; sh.li = 0; sh.vis_known = 0; sh.vis_occluded = 0; sh.hit_t = h.t; sh.view = tr_d;
       if (h.prim == -1) {
-        sh.colr = {LATE(cam).bg[0], LATE(cam).bg[1], LATE(cam).bg[2]};   // ray.cu:86
+        sh.colr = {LATE_AT(ka, cam).bg[0], LATE_AT(ka, cam).bg[1], LATE_AT(ka, cam).bg[2]};   // ray.cu:86
         sh.mcount = 0;
       } else {
         RtDeviceView S;   // view handed to the helpers of rt_kernels.h
-        S.tri_geom = LATE(tri_geom); S.tri_shade = LATE(tri_shade); S.spheres = spheres;
+        S.tri_geom = LATE_AT(ka, tri_geom); S.tri_shade = LATE_AT(ka, tri_shade); S.spheres = spheres;
         surface(S, tr_e, tr_d, h, sh.P, sh.N);
         if (h.prim >= 0) {
           const int32_t mesh = (int32_t)__float_as_uint(S.tri_geom[3 * h.prim + 2].y);
-          sh.mfirst = LATE(mesh_mat_first)[mesh]; sh.mcount = LATE(mesh_mat_count)[mesh];
+          sh.mfirst = LATE_AT(ka, mesh_mat_first)[mesh]; sh.mcount = LATE_AT(ka, mesh_mat_count)[mesh];
         } else { sh.mfirst = spheres[-2 - h.prim].mat_first; sh.mcount = spheres[-2 - h.prim].mat_count; }
       }
     } else if (phase == PH_SHADOW) {
@@ -652,12 +654,12 @@ __global__ __launch_bounds__(RT_WBLOCK, BOUNCE ? RT_WAVES_PER_SIMD_BOUNCE : RT_W
           } else phase = PH_DONE;
           break;
         }
-        const RtMaterial M = LATE(materials)[LATE(mat_index)[sh.mfirst + sh.mi]];
+        const RtMaterial M = LATE_AT(ka, materials)[LATE_AT(ka, mat_index)[sh.mfirst + sh.mi]];
         const RtVec3 P = sh.P, N = sh.N;
         if (M.type == RT_LAMBERT || M.type == RT_PHONG) {   // material.cu:15-24, lights.cu:260-367
           const int li = sh.li;
-          if (li >= LATE(n_lights)) { sh.mi++; sh.li = 0; continue; }
-          const RtLight L = LATE(lights)[li];
+          if (li >= LATE_AT(ka, n_lights)) { sh.mi++; sh.li = 0; continue; }
+          const RtLight L = LATE_AT(ka, lights)[li];
           if (L.type == RT_AMBIENT) {
             if (M.type == RT_LAMBERT) {
               sh.colr.x = sh.colr.x + M.col[0] * L.col[0]; sh.colr.y = sh.colr.y + M.col[1] * L.col[1]; sh.colr.z = sh.colr.z + M.col[2] * L.col[2];
@@ -669,7 +671,7 @@ __global__ __launch_bounds__(RT_WBLOCK, BOUNCE ? RT_WAVES_PER_SIMD_BOUNCE : RT_W
           else l = rt_normalized({L.pos[0] - P.x, L.pos[1] - P.y, L.pos[2] - P.z});
           const RtVec3 sP = {P.x + l.x * RT_EPS, P.y + l.y * RT_EPS, P.z + l.z * RT_EPS};
           if (L.type != RT_DIRECTIONAL) ldist = rt_len({L.pos[0] - sP.x, L.pos[1] - sP.y, L.pos[2] - sP.z});
-          if (LATE(cam).shadows) {   // ray.cu:56-72
+          if (LATE_AT(ka, cam).shadows) {   // ray.cu:56-72
             bool occluded;
             if (verdict >= 0) {   // the trace requested by this very step has come back
               occluded = verdict != 0; verdict = -1;
@@ -699,7 +701,7 @@ __global__ __launch_bounds__(RT_WBLOCK, BOUNCE ? RT_WAVES_PER_SIMD_BOUNCE : RT_W
           sh.colr.z = sh.colr.z + (M.col[2] * L.col[2]) * w;
           sh.li++;
         } else {
-          if (BOUNCE && sh.depth < LATE(cam).max_depth) {
+          if (BOUNCE && sh.depth < LATE_AT(ka, cam).max_depth) {
             const RtVec3 vd = sh.view;
             const float s2 = 2 * rt_dot(vd, N);
             const RtVec3 rl = rt_normalized({vd.x - N.x * s2, vd.y - N.y * s2, vd.z - N.z * s2});
