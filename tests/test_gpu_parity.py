@@ -178,6 +178,27 @@ def test_band_partition_reproduces_the_full_image(nranks):
     assert rays == fst["rays"]
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", ["meshMedBunny", "meshTransparentBunny"])
+def test_two_frames_in_flight_on_two_streams(name):
+    # the pipelining bench.py uses with several GPUs: one uploaded scene per stream, launches overlapping on the device;
+    # every frame must come out with the bytes of a frame rendered alone
+    import torch
+    w, h = 320, 208
+    scene = rt.Scene("scenes/%s.json" % name, w, h, 3)
+    scenes = [rt.DeviceScene(scene), rt.DeviceScene(scene)]
+    alone, _, _, _ = scenes[0].render_host(want_ids=False)
+    streams = [torch.cuda.Stream(device="cuda:0"), torch.cuda.Stream(device="cuda:0")]
+    bufs = [torch.zeros((h, w, 3), dtype=torch.uint8, device="cuda:0") for _ in range(6)]
+    torch.cuda.synchronize()
+    for k, buf in enumerate(bufs):
+        with torch.cuda.stream(streams[k % 2]):
+            scenes[k % 2].render_bands_into(buf.data_ptr(), 16, 0, 1, stream=streams[k % 2].cuda_stream)
+    torch.cuda.synchronize()
+    for buf in bufs:
+        assert np.array_equal(buf.cpu().numpy(), alone)
+
+
 SPOT_SCENE = """{
   "camera": {"fov": 50.0, "position": [0, 6, 14], "up": [0, 1, 0], "target": [0, 1, 0]},
   "objects": [
