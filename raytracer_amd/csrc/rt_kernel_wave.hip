@@ -207,6 +207,9 @@ __device__ __forceinline__ void trace_wave(const float4* __restrict__ nodes, int
         nb.z = __uint_as_float(r_first); nb.w = __uint_as_float(r_meta);
       } else {
         rem &= rem - 1u;
+#ifdef RT_PATH_GENERIC
+        tl.w[3]++;
+#endif
         na = nx_a; nb = nx_b;
         { const uint32_t c = (uint32_t)__builtin_ctz(rem | 0x100u); nx_a = rec(blk + NS * c); nx_b = rec(blk + NS * c + 1); }
         if (PATHS && uni(__float_as_uint(nb.w)) != 0u) tl.w[1]++;
