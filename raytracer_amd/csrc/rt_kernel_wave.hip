@@ -177,6 +177,79 @@ __device__ __forceinline__ void trace_wave(const float4* __restrict__ nodes, int
               und_m = mine_m & ~(acc_m | __builtin_amdgcn_ballot_w64(c_rej));                                                           \
             }                                                                                                                           \
           }
+#ifndef RT_NO_ASM_SCAN
+        if (presorted && !COUNT && !PATHS) {
+          // The same loop, its common part written out: children that every ray of the wave misses by more than the ray's
+          // largest margin never leave the assembly (consume the record, request the next sibling into the same eight
+          // registers, six products, head of the classification, one compare against the margin bound).  It ends at the
+          // first child some lane may hit, or with the last child, and hands the plane distances and the head over.
+          typedef uint32_t u8v __attribute__((ext_vector_type(8)));
+          for (;;) {
+            u8v nxv = {__float_as_uint(nx_a.x), __float_as_uint(nx_a.y), __float_as_uint(nx_a.z), __float_as_uint(nx_a.w),
+                       __float_as_uint(nx_b.x), __float_as_uint(nx_b.y), __float_as_uint(nx_b.z), __float_as_uint(nx_b.w)};
+            uint32_t prev, tmp;
+            uint64_t notrej;
+            float t0, t1, t2, t3, t4, t5, tn, tf, span, tc, x, r;
+            const uint64_t blk_bits = (uint64_t)blk;
+            asm volatile(
+                "L_scan_%=:\n"
+                "s_waitcnt lgkmcnt(0)\n"
+                "v_sub_f32 %[t0], s84, %[ex]\n"
+                "v_sub_f32 %[t1], s85, %[ex]\n"
+                "v_sub_f32 %[t2], s86, %[ey]\n"
+                "v_sub_f32 %[t3], s87, %[ey]\n"
+                "v_sub_f32 %[t4], s88, %[ez]\n"
+                "v_sub_f32 %[t5], s89, %[ez]\n"
+                "s_mov_b32 %[first], s90\n"
+                "s_mov_b32 %[meta], s91\n"
+                "s_mov_b32 %[prev], %[rem]\n"
+                "s_add_i32 %[tmp], %[rem], -1\n"
+                "s_and_b32 %[rem], %[rem], %[tmp]\n"
+                "s_or_b32 %[tmp], %[rem], 0x100\n"
+                "s_ff1_i32_b32 %[tmp], %[tmp]\n"
+                "s_lshl_b32 %[tmp], %[tmp], 5\n"
+                "s_load_dwordx8 s[84:91], %[blk], %[tmp] offset:0x0\n"
+                "v_mul_f32 %[t0], %[t0], %[ix]\n"
+                "v_mul_f32 %[t1], %[t1], %[ix]\n"
+                "v_mul_f32 %[t2], %[t2], %[iy]\n"
+                "v_mul_f32 %[t3], %[t3], %[iy]\n"
+                "v_mul_f32 %[t4], %[t4], %[iz]\n"
+                "v_mul_f32 %[t5], %[t5], %[iz]\n"
+                "v_max3_f32 %[tn], %[t0], %[t2], %[t4]\n"
+                "v_min3_f32 %[tf], %[t1], %[t3], %[t5]\n"
+                "v_cmp_lt_f32 vcc, 0, %[tn]\n"
+                "v_sub_f32 %[span], %[tf], %[tn]\n"
+                "v_cndmask_b32 %[tc], %[tf], %[tn], vcc\n"
+                "v_sub_f32 %[x], %[T], %[tc]\n"
+                "v_min3_f32 %[r], %[span], %[tf], %[x]\n"
+                "v_cmp_lt_f32_e64 %[nr], %[r], %[neb]\n"
+                "s_andn2_b64 %[nr], %[mine], %[nr]\n"
+                "s_cbranch_scc1 L_done_%=\n"
+                "s_cmp_lg_u32 %[rem], 0\n"
+                "s_cbranch_scc1 L_scan_%=\n"
+                "L_done_%=:\n"
+                "s_waitcnt lgkmcnt(0)\n"
+                : [nx] "+{s[84:91]}"(nxv), [rem] "+s"(rem), [first] "=&s"(r_first), [meta] "=&s"(r_meta), [prev] "=&s"(prev), [tmp] "=&s"(tmp),
+                  [nr] "=&s"(notrej), [t0] "=&v"(t0), [t1] "=&v"(t1), [t2] "=&v"(t2), [t3] "=&v"(t3), [t4] "=&v"(t4), [t5] "=&v"(t5),
+                  [tn] "=&v"(tn), [tf] "=&v"(tf), [span] "=&v"(span), [tc] "=&v"(tc), [x] "=&v"(x), [r] "=&v"(r)
+                : [blk] "s"(blk_bits), [mine] "s"(mine_m), [ex] "v"(e.x), [ey] "v"(e.y), [ez] "v"(e.z), [ix] "v"(inv.x), [iy] "v"(inv.y),
+                  [iz] "v"(inv.z), [T] "v"(hit.t), [neb] "v"(neg_eb)
+                : "vcc", "scc");
+            nx_a = float4{__uint_as_float(nxv[0]), __uint_as_float(nxv[1]), __uint_as_float(nxv[2]), __uint_as_float(nxv[3])};
+            nx_b = float4{__uint_as_float(nxv[4]), __uint_as_float(nxv[5]), __uint_as_float(nxv[6]), __uint_as_float(nxv[7])};
+            c_cur = (uint32_t)__builtin_ctz(prev);
+            acc_m = 0ull; und_m = 0ull;
+            if (notrej == 0ull) break;   // the last child, missed by everybody
+            RtSlabHead hd;
+            hd.tN = tn; hd.tF = tf; hd.span = span; hd.front = tn > 0.f; hd.tc = tc; hd.x = x; hd.r = r;
+            bool c_acc, c_rej;
+            rt_node_slab_tail(hd, t0, t1, t2, t3, t4, t5, hit.t, c_acc, c_rej);
+            acc_m = __builtin_amdgcn_ballot_w64(c_acc) & mine_m;
+            und_m = mine_m & ~(acc_m | __builtin_amdgcn_ballot_w64(c_rej));
+            if ((acc_m | und_m) != 0ull || rem == 0u) break;
+          }
+        } else
+#endif
         if (presorted) {
           RT_SCAN_LOOP(const float side = dx0, {
             const float tx0 = dx0 * inv.x, tx1 = dx1 * inv.x, ty0 = dy0 * inv.y, ty1 = dy1 * inv.y, tz0 = dz0 * inv.z, tz1 = dz1 * inv.z;
