@@ -263,7 +263,89 @@ __device__ __forceinline__ void trace_wave(const float4* __restrict__ nodes, int
               und_m = mine_m & ~(acc_m | __builtin_amdgcn_ballot_w64(c_rej));
             }
           })
-        } else {
+        }
+#ifndef RT_NO_ASM_SCAN
+        else if (!COUNT && !PATHS) {
+          // Zero direction pattern, common part in assembly as above: a child leaves it only if some ray of the wave has its
+          // origin within the child's extent on every zero axis (rt_node_zero_outside says no for everybody otherwise).
+          typedef uint32_t u8v __attribute__((ext_vector_type(8)));
+#define RT_ZERO_AXIS_ASM(D0, D1, COMBINE)                                                                                  \
+              "v_min_f32_e64 %[mn], -%[" D0 "], %[" D1 "]\n"                                                               \
+              "v_max_f32_e64 %[mx], -%[" D0 "], %[" D1 "]\n"                                                               \
+              "v_cmp_gt_f32 vcc, 0, %[mn]\n"                                                                               \
+              "v_cmp_gt_f32_e64 %[sq], %[mx], %[side]\n"                                                                   \
+              "s_and_b64 %[sq], %[sq], vcc\n" COMBINE
+#define RT_ZERO_FIRST "s_mov_b64 %[nr], %[sq]\n"
+#define RT_ZERO_NEXT "s_or_b64 %[nr], %[nr], %[sq]\n"
+#define RT_ZERO_SCAN(ZX, ZY, ZZ, AXES_ASM)                                                                                  \
+          for (;;) {                                                                                                       \
+            u8v nxv = {__float_as_uint(nx_a.x), __float_as_uint(nx_a.y), __float_as_uint(nx_a.z), __float_as_uint(nx_a.w),  \
+                       __float_as_uint(nx_b.x), __float_as_uint(nx_b.y), __float_as_uint(nx_b.z), __float_as_uint(nx_b.w)}; \
+            uint32_t prev, tmp;                                                                                            \
+            uint64_t notrej, sq;                                                                                           \
+            float d0, d1, d2, d3, d4, d5, side, mn, mx;                                                                    \
+            const uint64_t blk_bits = (uint64_t)blk;                                                                       \
+            asm volatile(                                                                                                  \
+                "L_zscan_%=:\n"                                                                                            \
+                "s_waitcnt lgkmcnt(0)\n"                                                                                   \
+                "v_sub_f32 %[d0], s84, %[ex]\n"                                                                            \
+                "v_sub_f32 %[d1], s85, %[ex]\n"                                                                            \
+                "v_sub_f32 %[d2], s86, %[ey]\n"                                                                            \
+                "v_sub_f32 %[d3], s87, %[ey]\n"                                                                            \
+                "v_sub_f32 %[d4], s88, %[ez]\n"                                                                            \
+                "v_sub_f32 %[d5], s89, %[ez]\n"                                                                            \
+                "v_mov_b32 %[side], s84\n"                                                                                 \
+                "v_sub_f32 %[side], s85, %[side]\n"                                                                        \
+                "s_mov_b32 %[first], s90\n"                                                                                \
+                "s_mov_b32 %[meta], s91\n"                                                                                 \
+                "s_mov_b32 %[prev], %[rem]\n"                                                                              \
+                "s_add_i32 %[tmp], %[rem], -1\n"                                                                           \
+                "s_and_b32 %[rem], %[rem], %[tmp]\n"                                                                       \
+                "s_or_b32 %[tmp], %[rem], 0x100\n"                                                                         \
+                "s_ff1_i32_b32 %[tmp], %[tmp]\n"                                                                           \
+                "s_lshl_b32 %[tmp], %[tmp], 5\n"                                                                           \
+                "s_load_dwordx8 s[84:91], %[blk], %[tmp] offset:0x0\n"                                                     \
+                AXES_ASM                                                                                                   \
+                "s_andn2_b64 %[nr], %[mine], %[nr]\n"                                                                      \
+                "s_cbranch_scc1 L_zdone_%=\n"                                                                              \
+                "s_cmp_lg_u32 %[rem], 0\n"                                                                                 \
+                "s_cbranch_scc1 L_zscan_%=\n"                                                                              \
+                "L_zdone_%=:\n"                                                                                            \
+                "s_waitcnt lgkmcnt(0)\n"                                                                                   \
+                : [nx] "+{s[84:91]}"(nxv), [rem] "+s"(rem), [first] "=&s"(r_first), [meta] "=&s"(r_meta), [prev] "=&s"(prev),   \
+                  [tmp] "=&s"(tmp), [nr] "=&s"(notrej), [sq] "=&s"(sq), [d0] "=&v"(d0), [d1] "=&v"(d1), [d2] "=&v"(d2),      \
+                  [d3] "=&v"(d3), [d4] "=&v"(d4), [d5] "=&v"(d5), [side] "=&v"(side), [mn] "=&v"(mn), [mx] "=&v"(mx)         \
+                : [blk] "s"(blk_bits), [mine] "s"(mine_m), [ex] "v"(e.x), [ey] "v"(e.y), [ez] "v"(e.z)                      \
+                : "vcc", "scc");                                                                                           \
+            nx_a = float4{__uint_as_float(nxv[0]), __uint_as_float(nxv[1]), __uint_as_float(nxv[2]), __uint_as_float(nxv[3])}; \
+            nx_b = float4{__uint_as_float(nxv[4]), __uint_as_float(nxv[5]), __uint_as_float(nxv[6]), __uint_as_float(nxv[7])}; \
+            c_cur = (uint32_t)__builtin_ctz(prev);                                                                         \
+            acc_m = 0ull; und_m = 0ull;                                                                                    \
+            if (notrej == 0ull) break;   /* the last child, beside everybody */                                            \
+            {                                                                                                              \
+              const float dlo[3] = {d0, d2, d4}, dhi[3] = {d1, d3, d5};                                                    \
+              bool c_acc, c_rej;                                                                                           \
+              rt_node_slab_zero_d<ZX, ZY, ZZ>(dlo, dhi, side, inv, hit.t, c_acc, c_rej);                                   \
+              acc_m = __builtin_amdgcn_ballot_w64(c_acc) & mine_m;                                                         \
+              und_m = mine_m & ~(acc_m | __builtin_amdgcn_ballot_w64(c_rej));                                              \
+            }                                                                                                              \
+            if ((acc_m | und_m) != 0ull || rem == 0u) break;                                                               \
+          }
+          switch (zpat) {
+            case 1u: RT_ZERO_SCAN(true, false, false, RT_ZERO_AXIS_ASM("d0", "d1", RT_ZERO_FIRST)) break;
+            case 2u: RT_ZERO_SCAN(false, true, false, RT_ZERO_AXIS_ASM("d2", "d3", RT_ZERO_FIRST)) break;
+            case 3u: RT_ZERO_SCAN(true, true, false, RT_ZERO_AXIS_ASM("d0", "d1", RT_ZERO_FIRST) RT_ZERO_AXIS_ASM("d2", "d3", RT_ZERO_NEXT)) break;
+            case 4u: RT_ZERO_SCAN(false, false, true, RT_ZERO_AXIS_ASM("d4", "d5", RT_ZERO_FIRST)) break;
+            case 5u: RT_ZERO_SCAN(true, false, true, RT_ZERO_AXIS_ASM("d0", "d1", RT_ZERO_FIRST) RT_ZERO_AXIS_ASM("d4", "d5", RT_ZERO_NEXT)) break;
+            default: RT_ZERO_SCAN(false, true, true, RT_ZERO_AXIS_ASM("d2", "d3", RT_ZERO_FIRST) RT_ZERO_AXIS_ASM("d4", "d5", RT_ZERO_NEXT)) break;
+          }
+#undef RT_ZERO_SCAN
+#undef RT_ZERO_AXIS_ASM
+#undef RT_ZERO_FIRST
+#undef RT_ZERO_NEXT
+        }
+#endif
+        else {
           switch (zpat) {
             case 1u: RT_SCAN_LOOP(const float side = nx_a.y - nx_a.x, RT_CLASSIFY_ZERO(true, false, false)) break;
             case 2u: RT_SCAN_LOOP(const float side = nx_a.y - nx_a.x, RT_CLASSIFY_ZERO(false, true, false)) break;
