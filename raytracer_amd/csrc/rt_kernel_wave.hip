@@ -109,12 +109,17 @@ __device__ __forceinline__ void trace_wave(const float4* __restrict__ nodes, int
     // Node records reach the SGPRs through the scalar cache.  The record of the child that will be tested next is
     // always requested as soon as it is known (next sibling: before the current child is classified; first child of
     // a branch: on descent or ascent), so its latency hides behind the classification.
-    float4 nx_a = {0, 0, 0, 0}, nx_b = {0, 0, 0, 0};
+    // (one 8-word value: the assembly loops keep it in a fixed block of eight scalar registers, and the loads around
+    // them go straight into that block)
+    typedef float f8 __attribute__((ext_vector_type(8)));
+    typedef const __attribute__((address_space(4))) f8* cnode8_ptr;
+    auto rec8 = [](cnode_ptr p) { return *(cnode8_ptr)p; };
+    f8 nx = {0, 0, 0, 0, 0, 0, 0, 0};
     // margin that no node of this tree exceeds for this ray (the root's planes bound every node's)
     float neg_eb = 0.f;
     if (presorted) { const float4 ra = rec(cnodes), rb = rec(cnodes + 1); neg_eb = -rt_slab_margin_bound(ra.x, ra.y, ra.z, ra.w, rb.x, rb.y, e, inv, hit.t); }
     cnode_ptr blk = cnodes + NS * top_first;   // records of the current branch's children
-    { const uint32_t c = (uint32_t)__builtin_ctz(rem | 0x100u); nx_a = rec(blk + NS * c); nx_b = rec(blk + NS * c + 1); }
+    { const uint32_t c = (uint32_t)__builtin_ctz(rem | 0x100u); nx = rec8(blk + NS * c); }
     // `mine_m` = lanes that entered the current branch and are still undecided.  It only changes when the branch changes or
     // a lane gets decided; whenever it becomes empty the branch is abandoned by clearing `rem`, so that the loop head has
     // a single scalar test.
@@ -129,7 +134,7 @@ __device__ __forceinline__ void trace_wave(const float4* __restrict__ nodes, int
         if (mine_m == 0ull) { rem = 0u; continue; }
         blk = cnodes + NS * top_first;
         const uint32_t c = (uint32_t)__builtin_ctz(rem);   // entries are only pushed with children left
-        nx_a = rec(blk + NS * c); nx_b = rec(blk + NS * c + 1);
+        nx = rec8(blk + NS * c);
         continue;
       }
       float4 na, nb;
@@ -142,21 +147,21 @@ __device__ __forceinline__ void trace_wave(const float4* __restrict__ nodes, int
         // sibling is tied to those results, so it is issued afterwards and its data may land in the very registers the
         // record occupied: nothing is copied from "next" to "current".  Whoever needs the planes again (the exact test,
         // rarely) reads the record once more.
-        uint32_t c_cur = 0u, r_first = 0u, r_meta = 0u;
+        uint32_t rem_cur = 1u, r_first = 0u, r_meta = 0u;   // rem_cur: `rem` before the child just tested was taken out of it
         // (RT_SCAN_LOOP stamps the loop out once per kind of node test: CLASSIFY turns the six differences into acc_m / und_m)
 #define RT_SCAN_LOOP(SIDE, ...)                                                                                                         \
         for (;;) {                                                                                                                      \
-          c_cur = (uint32_t)__builtin_ctz(rem);                                                                                         \
+          rem_cur = rem;                                                                                                                \
           rem &= rem - 1u;                                                                                                              \
-          const float dx0 = nx_a.x - e.x, dx1 = nx_a.y - e.x, dy0 = nx_a.z - e.y, dy1 = nx_a.w - e.y, dz0 = nx_b.x - e.z, dz1 = nx_b.y - e.z; \
+          const float dx0 = nx[0] - e.x, dx1 = nx[1] - e.x, dy0 = nx[2] - e.y, dy1 = nx[3] - e.y, dz0 = nx[4] - e.z, dz1 = nx[5] - e.z;             \
           SIDE;                                                                                                                         \
-          r_first = uni(__float_as_uint(nx_b.z)); r_meta = uni(__float_as_uint(nx_b.w));                                                \
+          r_first = uni(__float_as_uint(nx[6])); r_meta = uni(__float_as_uint(nx[7]));                                                  \
           {                                                                                                                             \
             /* next sibling ("child 8" after the last one is the first record of the next block or the pad record) */                  \
             uint32_t off = (uint32_t)__builtin_ctz(rem | 0x100u) * 32u;   /* byte offset of that record within the block */             \
             asm volatile("" : "+s"(off) : "v"(dx0), "v"(dx1), "v"(dy0), "v"(dy1), "v"(dz0), "v"(dz1), "v"(side), "s"(r_first), "s"(r_meta)); \
             const cnode_ptr rp = (cnode_ptr)((const __attribute__((address_space(4))) char*)blk + off);                                 \
-            nx_a = rec(rp); nx_b = rec(rp + 1);                                                                                         \
+            nx = rec8(rp);                                                                                         \
           }                                                                                                                             \
           if (PATHS && r_meta != 0u) tl.w[1]++;                                                                                         \
           if (COUNT && ((mine_m >> lane) & 1ull)) tl.node++;   /* w[1]: iterations the plain variant also makes */                      \
@@ -183,10 +188,7 @@ __device__ __forceinline__ void trace_wave(const float4* __restrict__ nodes, int
           // largest margin never leave the assembly (consume the record, request the next sibling into the same eight
           // registers, six products, head of the classification, one compare against the margin bound).  It ends at the
           // first child some lane may hit, or with the last child, and hands the plane distances and the head over.
-          typedef uint32_t u8v __attribute__((ext_vector_type(8)));
           for (;;) {
-            u8v nxv = {__float_as_uint(nx_a.x), __float_as_uint(nx_a.y), __float_as_uint(nx_a.z), __float_as_uint(nx_a.w),
-                       __float_as_uint(nx_b.x), __float_as_uint(nx_b.y), __float_as_uint(nx_b.z), __float_as_uint(nx_b.w)};
             uint32_t prev, tmp;
             uint64_t notrej;
             float t0, t1, t2, t3, t4, t5, tn, tf, span, tc, x, r;
@@ -229,15 +231,13 @@ __device__ __forceinline__ void trace_wave(const float4* __restrict__ nodes, int
                 "s_cbranch_scc1 L_scan_%=\n"
                 "L_done_%=:\n"
                 "s_waitcnt lgkmcnt(0)\n"
-                : [nx] "+{s[84:91]}"(nxv), [rem] "+s"(rem), [first] "=&s"(r_first), [meta] "=&s"(r_meta), [prev] "=&s"(prev), [tmp] "=&s"(tmp),
+                : [nx] "+{s[84:91]}"(nx), [rem] "+s"(rem), [first] "=&s"(r_first), [meta] "=&s"(r_meta), [prev] "=&s"(prev), [tmp] "=&s"(tmp),
                   [nr] "=&s"(notrej), [t0] "=&v"(t0), [t1] "=&v"(t1), [t2] "=&v"(t2), [t3] "=&v"(t3), [t4] "=&v"(t4), [t5] "=&v"(t5),
                   [tn] "=&v"(tn), [tf] "=&v"(tf), [span] "=&v"(span), [tc] "=&v"(tc), [x] "=&v"(x), [r] "=&v"(r)
                 : [blk] "s"(blk_bits), [mine] "s"(mine_m), [ex] "v"(e.x), [ey] "v"(e.y), [ez] "v"(e.z), [ix] "v"(inv.x), [iy] "v"(inv.y),
                   [iz] "v"(inv.z), [T] "v"(hit.t), [neb] "v"(neg_eb)
                 : "vcc", "scc");
-            nx_a = float4{__uint_as_float(nxv[0]), __uint_as_float(nxv[1]), __uint_as_float(nxv[2]), __uint_as_float(nxv[3])};
-            nx_b = float4{__uint_as_float(nxv[4]), __uint_as_float(nxv[5]), __uint_as_float(nxv[6]), __uint_as_float(nxv[7])};
-            c_cur = (uint32_t)__builtin_ctz(prev);
+            rem_cur = uni(prev);
             acc_m = 0ull; und_m = 0ull;
             if (notrej == 0ull) break;   // the last child, missed by everybody
             RtSlabHead hd;
@@ -268,7 +268,6 @@ __device__ __forceinline__ void trace_wave(const float4* __restrict__ nodes, int
         else if (!COUNT && !PATHS) {
           // Zero direction pattern, common part in assembly as above: a child leaves it only if some ray of the wave has its
           // origin within the child's extent on every zero axis (rt_node_zero_outside says no for everybody otherwise).
-          typedef uint32_t u8v __attribute__((ext_vector_type(8)));
 #define RT_ZERO_AXIS_ASM(D0, D1, COMBINE)                                                                                  \
               "v_min_f32_e64 %[mn], -%[" D0 "], %[" D1 "]\n"                                                               \
               "v_max_f32_e64 %[mx], -%[" D0 "], %[" D1 "]\n"                                                               \
@@ -279,8 +278,6 @@ __device__ __forceinline__ void trace_wave(const float4* __restrict__ nodes, int
 #define RT_ZERO_NEXT "s_or_b64 %[nr], %[nr], %[sq]\n"
 #define RT_ZERO_SCAN(ZX, ZY, ZZ, AXES_ASM)                                                                                  \
           for (;;) {                                                                                                       \
-            u8v nxv = {__float_as_uint(nx_a.x), __float_as_uint(nx_a.y), __float_as_uint(nx_a.z), __float_as_uint(nx_a.w),  \
-                       __float_as_uint(nx_b.x), __float_as_uint(nx_b.y), __float_as_uint(nx_b.z), __float_as_uint(nx_b.w)}; \
             uint32_t prev, tmp;                                                                                            \
             uint64_t notrej, sq;                                                                                           \
             float d0, d1, d2, d3, d4, d5, side, mn, mx;                                                                    \
@@ -312,14 +309,12 @@ __device__ __forceinline__ void trace_wave(const float4* __restrict__ nodes, int
                 "s_cbranch_scc1 L_zscan_%=\n"                                                                              \
                 "L_zdone_%=:\n"                                                                                            \
                 "s_waitcnt lgkmcnt(0)\n"                                                                                   \
-                : [nx] "+{s[84:91]}"(nxv), [rem] "+s"(rem), [first] "=&s"(r_first), [meta] "=&s"(r_meta), [prev] "=&s"(prev),   \
+                : [nx] "+{s[84:91]}"(nx), [rem] "+s"(rem), [first] "=&s"(r_first), [meta] "=&s"(r_meta), [prev] "=&s"(prev),   \
                   [tmp] "=&s"(tmp), [nr] "=&s"(notrej), [sq] "=&s"(sq), [d0] "=&v"(d0), [d1] "=&v"(d1), [d2] "=&v"(d2),      \
                   [d3] "=&v"(d3), [d4] "=&v"(d4), [d5] "=&v"(d5), [side] "=&v"(side), [mn] "=&v"(mn), [mx] "=&v"(mx)         \
                 : [blk] "s"(blk_bits), [mine] "s"(mine_m), [ex] "v"(e.x), [ey] "v"(e.y), [ez] "v"(e.z)                      \
                 : "vcc", "scc");                                                                                           \
-            nx_a = float4{__uint_as_float(nxv[0]), __uint_as_float(nxv[1]), __uint_as_float(nxv[2]), __uint_as_float(nxv[3])}; \
-            nx_b = float4{__uint_as_float(nxv[4]), __uint_as_float(nxv[5]), __uint_as_float(nxv[6]), __uint_as_float(nxv[7])}; \
-            c_cur = (uint32_t)__builtin_ctz(prev);                                                                         \
+            rem_cur = uni(prev);                                                                                           \
             acc_m = 0ull; und_m = 0ull;                                                                                    \
             if (notrej == 0ull) break;   /* the last child, beside everybody */                                            \
             {                                                                                                              \
@@ -347,26 +342,29 @@ __device__ __forceinline__ void trace_wave(const float4* __restrict__ nodes, int
 #endif
         else {
           switch (zpat) {
-            case 1u: RT_SCAN_LOOP(const float side = nx_a.y - nx_a.x, RT_CLASSIFY_ZERO(true, false, false)) break;
-            case 2u: RT_SCAN_LOOP(const float side = nx_a.y - nx_a.x, RT_CLASSIFY_ZERO(false, true, false)) break;
-            case 3u: RT_SCAN_LOOP(const float side = nx_a.y - nx_a.x, RT_CLASSIFY_ZERO(true, true, false)) break;
-            case 4u: RT_SCAN_LOOP(const float side = nx_a.y - nx_a.x, RT_CLASSIFY_ZERO(false, false, true)) break;
-            case 5u: RT_SCAN_LOOP(const float side = nx_a.y - nx_a.x, RT_CLASSIFY_ZERO(true, false, true)) break;
-            default: RT_SCAN_LOOP(const float side = nx_a.y - nx_a.x, RT_CLASSIFY_ZERO(false, true, true)) break;
+            case 1u: RT_SCAN_LOOP(const float side = nx[1] - nx[0], RT_CLASSIFY_ZERO(true, false, false)) break;
+            case 2u: RT_SCAN_LOOP(const float side = nx[1] - nx[0], RT_CLASSIFY_ZERO(false, true, false)) break;
+            case 3u: RT_SCAN_LOOP(const float side = nx[1] - nx[0], RT_CLASSIFY_ZERO(true, true, false)) break;
+            case 4u: RT_SCAN_LOOP(const float side = nx[1] - nx[0], RT_CLASSIFY_ZERO(false, false, true)) break;
+            case 5u: RT_SCAN_LOOP(const float side = nx[1] - nx[0], RT_CLASSIFY_ZERO(true, false, true)) break;
+            default: RT_SCAN_LOOP(const float side = nx[1] - nx[0], RT_CLASSIFY_ZERO(false, true, true)) break;
           }
         }
 #undef RT_SCAN_LOOP
 #undef RT_CLASSIFY_ZERO
         na = float4{0.f, 0.f, 0.f, 0.f}; nb = float4{0.f, 0.f, 0.f, 0.f};
-        if (und_m) { na = rec(blk + NS * c_cur); nb = rec(blk + NS * c_cur + 1); }   // the exact test wants the planes again
+        if (und_m) {   // the exact test wants the planes again
+          const uint32_t c_cur = (uint32_t)__builtin_ctz(rem_cur);
+          na = rec(blk + NS * c_cur); nb = rec(blk + NS * c_cur + 1);
+        }
         nb.z = __uint_as_float(r_first); nb.w = __uint_as_float(r_meta);
       } else {
         rem &= rem - 1u;
 #ifdef RT_PATH_GENERIC
         tl.w[3]++;
 #endif
-        na = nx_a; nb = nx_b;
-        { const uint32_t c = (uint32_t)__builtin_ctz(rem | 0x100u); nx_a = rec(blk + NS * c); nx_b = rec(blk + NS * c + 1); }
+        na = float4{nx[0], nx[1], nx[2], nx[3]}; nb = float4{nx[4], nx[5], nx[6], nx[7]};
+        { const uint32_t c = (uint32_t)__builtin_ctz(rem | 0x100u); nx = rec8(blk + NS * c); }
         if (PATHS && uni(__float_as_uint(nb.w)) != 0u) tl.w[1]++;
         if (COUNT && ((mine_m >> lane) & 1ull)) tl.node++;
         if (!any_zero) {
@@ -420,7 +418,7 @@ __device__ __forceinline__ void trace_wave(const float4* __restrict__ nodes, int
         top_first = first; rem = crem; top_mask = acc_m; mine_m = acc_m;
         blk = cnodes + NS * top_first;
         const uint32_t c = (uint32_t)__builtin_ctz(rem);
-        nx_a = rec(blk + NS * c); nx_b = rec(blk + NS * c + 1);
+        nx = rec8(blk + NS * c);
         continue;
       }
       const int32_t count = (int32_t)meta;
