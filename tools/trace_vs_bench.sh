@@ -1,3 +1,6 @@
+#!/bin/bash
+# The headline benchmark without the tracer, under rocprofv3 --kernel-trace --stats, and without it again, on the same
+# box (run on the GPU box from the repository root): the tracer's average kernel duration beside bench.py's own.
 set -e
 root=$(pwd); out=$root/gpurun_out/prof_tb; rm -rf $out; mkdir -p $out; export TMPDIR=/tmp
 python3 bench.py --no-cpu-baseline | python3 -c "import sys,json; j=json.loads(sys.stdin.read()); print('bench', j['ms_per_step'], j['roofline']['kernel_ms'])"
