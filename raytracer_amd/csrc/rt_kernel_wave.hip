@@ -31,6 +31,11 @@ namespace {
 #define RT_WTILE_W (8 * RT_WAVES_X)
 #define RT_WTILE_H (8 * (RT_WBLOCK / 64) / RT_WAVES_X)
 
+#define RT_DIES 8u        // XCDs of an MI355X; workgroup i of a launch starts on die i % 8
+#ifndef RT_STRIP_W
+#define RT_STRIP_W 4u     // tile columns per strip
+#endif
+
 struct Tally { uint32_t rays, shadow, node, leaf, tri, sph, traced; uint32_t w[8]; };   // w: wave-level path counts (lane 0, instrumented variant)
 
 // The wave's traversal stack lives in four VGPRs: entry i is held by lane i (depth <= 20 < 64) and is
@@ -583,6 +588,9 @@ struct RtWaveArgs {
   const int32_t* mesh_mat_first; const int32_t* mesh_mat_count;
   int n_spheres, n_lights, has_oct, n_wnodes;
   uint8_t* rgb; int32_t* ids; float* ts; unsigned long long* counters_all; int tally;
+  // Tiles of the launch and how they are dealt to the chip's dies (see tile_of): tiles per row / column, strips of
+  // RT_STRIP_W tile columns per die (0: a plain two-dimensional grid, one workgroup per tile)
+  uint32_t tiles_x, tiles_y, strips_per_die;
   RtQueues wf;
 };
 #define RT_WAVE_ARGS_OFFSET 16   // two pointers in front of the block
@@ -623,18 +631,35 @@ __global__ __launch_bounds__(RT_WBLOCK, BOUNCE ? RT_WAVES_PER_SIMD_BOUNCE : RT_W
   // coordinates are needed at the start, after the primary ray and at the end; they are derived again each time
   // from an opaque copy of the thread index, so that none of them occupies a register (or a spill slot) in between.
   struct Pixel { int col, lrow, row, orow; bool valid; };   // (derived per use, see below)
+  // Tile of this workgroup.  Workgroups go to the eight dies (XCDs) of the chip in turn, each die with its own L2: so
+  // that a die keeps meeting the same part of the scene, workgroup i renders a tile of die i % 8's own strips - strips of
+  // RT_STRIP_W tile columns, dealt to the dies round-robin across the picture (balanced, yet each die sees an eighth of
+  // it) - in row order.  A slot beyond the picture (ragged widths) has no tile: its lanes are invalid.
+  struct Tile { uint32_t x, y; };
+  auto tile_of = [&]() {
+    Tile t = {blockIdx.x, blockIdx.y};
+    const uint32_t spd = LATE(strips_per_die);
+    if (spd != 0u) {
+      const uint32_t die = blockIdx.x % RT_DIES, j = blockIdx.x / RT_DIES, per_row = spd * RT_STRIP_W;
+      const uint32_t in_row = j % per_row;
+      t.y = j / per_row;
+      t.x = ((in_row / RT_STRIP_W) * RT_DIES + die) * RT_STRIP_W + in_row % RT_STRIP_W;
+    }
+    return t;
+  };
   auto pixel_of = [&](int t) {
     asm volatile("" : "+v"(t));
     const int w = t >> 6, l = t & 63;
+    const Tile tile = tile_of();
     const RowMap rows = LATE_STRUCT(rows);
     const int W = LATE(cam).width, H = LATE(cam).height;
     Pixel p;
     if (rows.small) {
-      p.col = blockIdx.x * (RT_WTILE_W / 2) + (w % RT_WAVES_X) * 4 + (l & 3);
-      p.lrow = blockIdx.y * (RT_WTILE_H / 2) + (w / RT_WAVES_X) * 4 + ((l >> 2) & 3);
+      p.col = tile.x * (RT_WTILE_W / 2) + (w % RT_WAVES_X) * 4 + (l & 3);
+      p.lrow = tile.y * (RT_WTILE_H / 2) + (w / RT_WAVES_X) * 4 + ((l >> 2) & 3);
     } else {
-      p.col = blockIdx.x * RT_WTILE_W + (w % RT_WAVES_X) * 8 + (l & 7);
-      p.lrow = blockIdx.y * RT_WTILE_H + (w / RT_WAVES_X) * 8 + (l >> 3);
+      p.col = tile.x * RT_WTILE_W + (w % RT_WAVES_X) * 8 + (l & 7);
+      p.lrow = tile.y * RT_WTILE_H + (w / RT_WAVES_X) * 8 + (l >> 3);
     }
     p.row = rows.row0 + (p.lrow / rows.band_rows) * rows.band_stride + p.lrow % rows.band_rows;
     p.orow = rows.compact ? p.lrow : p.row;
@@ -943,7 +968,7 @@ __global__ __launch_bounds__(RT_WBLOCK, BOUNCE ? RT_WAVES_PER_SIMD_BOUNCE : RT_W
   if (ts && !queued && lane == 0) {
     const unsigned long long wt_end = __builtin_amdgcn_s_memrealtime();
     const uint32_t hw = __builtin_amdgcn_s_getreg((31 << 11) | (0 << 6) | 4), xcc = __builtin_amdgcn_s_getreg((31 << 11) | (0 << 6) | 20);
-    uint32_t* o = (uint32_t*)ts + 4 * (size_t)((blockIdx.y * gridDim.x + blockIdx.x) * (RT_WBLOCK / 64) + (tid >> 6));
+    uint32_t* o = (uint32_t*)ts + 4 * (size_t)((tile_of().y * LATE(tiles_x) + tile_of().x) * (RT_WBLOCK / 64) + (tid >> 6));
     o[0] = (uint32_t)wt_start; o[1] = (uint32_t)wt_end; o[2] = hw; o[3] = xcc;
   }
 #endif
@@ -973,6 +998,13 @@ void rt_launch_wave_kernel(const RtDeviceView& V, const RowMap& rows, bool bounc
     grid = dim3((wf.n_in + per_block - 1) / per_block, 1); bounce = true;
   }
   RtWaveArgs A;
+  A.tiles_x = grid.x; A.tiles_y = grid.y; A.strips_per_die = 0u;
+  static const bool plain_grid = getenv("RT_AMD_PLAIN_GRID") != nullptr;   // measurements
+  if (!wf.in && RT_WBLOCK == 64 && !plain_grid) {   // tiles dealt to the dies in strips: a one-dimensional grid of 8 x strips x rows slots
+    const uint32_t strips = (grid.x + RT_STRIP_W - 1u) / RT_STRIP_W;
+    A.strips_per_die = (strips + RT_DIES - 1u) / RT_DIES;
+    grid = dim3(RT_DIES * A.strips_per_die * RT_STRIP_W * grid.y, 1);
+  }
   A.cam = V.cam; A.rows = rows; A.tri_geom = V.tri_geom; A.tri_shade = V.tri_shade;
   A.spheres = V.spheres; A.lights = V.lights; A.materials = V.materials; A.mat_index = V.mat_index;
   A.mesh_mat_first = V.mesh_mat_first; A.mesh_mat_count = V.mesh_mat_count;
