@@ -634,16 +634,18 @@ __global__ __launch_bounds__(RT_WBLOCK, BOUNCE ? RT_WAVES_PER_SIMD_BOUNCE : RT_W
   // Tile of this workgroup.  Workgroups go to the eight dies (XCDs) of the chip in turn, each die with its own L2: so
   // that a die keeps meeting the same part of the scene, workgroup i renders a tile of die i % 8's own strips - strips of
   // RT_STRIP_W tile columns, dealt to the dies round-robin across the picture (balanced, yet each die sees an eighth of
-  // it) - in row order.  A slot beyond the picture (ragged widths) has no tile: its lanes are invalid.
+  // it) - one strip after the other, each from the top down.  A slot beyond the picture (ragged widths) has no tile:
+  // its lanes are invalid.  (Measured on the headline frame: 2.88 ms with a plain grid, 2.72 ms with the strips walked
+  // row by row, 2.70 ms strip by strip; strips 2 or 8 columns wide and square blocks of 4 to 16 tiles: 2.71 to 2.84 ms.)
   struct Tile { uint32_t x, y; };
   auto tile_of = [&]() {
     Tile t = {blockIdx.x, blockIdx.y};
     const uint32_t spd = LATE(strips_per_die);
     if (spd != 0u) {
-      const uint32_t die = blockIdx.x % RT_DIES, j = blockIdx.x / RT_DIES, per_row = spd * RT_STRIP_W;
-      const uint32_t in_row = j % per_row;
-      t.y = j / per_row;
-      t.x = ((in_row / RT_STRIP_W) * RT_DIES + die) * RT_STRIP_W + in_row % RT_STRIP_W;
+      const uint32_t die = blockIdx.x % RT_DIES, j = blockIdx.x / RT_DIES;
+      const uint32_t per_strip = RT_STRIP_W * LATE(tiles_y), strip = j / per_strip, in_strip = j % per_strip;
+      t.y = in_strip / RT_STRIP_W;
+      t.x = (strip * RT_DIES + die) * RT_STRIP_W + in_strip % RT_STRIP_W;
     }
     return t;
   };
