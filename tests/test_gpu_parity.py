@@ -227,6 +227,35 @@ def test_spot_lights_synthetic_scene(tmp_path):
         _check_scene(str(q), 200, 120)
 
 
+PARALLEL_LIGHTS_SCENE = """{
+  "camera": {"fov": 45.0, "position": [3, 9, 12], "up": [0, 1, 0], "target": [0, 1.5, 0]},
+  "objects": [
+    {"__type__": "mesh", "file_path": "meshes/large_plane.obj", "materials": ["white_lambert"]},
+    {"__type__": "mesh", "file_path": "meshes/bunny_med.obj", "materials": ["red_lambert", "white_bph_1000"],
+     "scaling": [2, 2, 2], "rotation": [0, 30, 0], "translation": [0, 0.2, 0]}
+  ],
+  "lights": [
+    {"__type__": "directional_light", "direction": [0, -1, 0], "color": [0.2, 0.2, 0.2]},
+    {"__type__": "directional_light", "direction": [-1, 0, 0], "color": [0.2, 0.1, 0.1]},
+    {"__type__": "directional_light", "direction": [0, 0, -1], "color": [0.1, 0.2, 0.1]},
+    {"__type__": "directional_light", "direction": [-1, -1, 0], "color": [0.1, 0.1, 0.2]},
+    {"__type__": "directional_light", "direction": [0, -1, -1], "color": [0.2, 0.2, 0.1]},
+    {"__type__": "directional_light", "direction": [1, -1, 0], "color": [0.1, 0.1, 0.1]},
+    {"__type__": "directional_light", "direction": [-1, 0, -1], "color": [0.1, 0.2, 0.2]},
+    {"__type__": "ambient_light", "color": [0.1, 0.1, 0.1]}
+  ],
+  "params": {"background_color": [0.3, 0.3, 0.4], "enable_shadows": "true"}
+}"""
+
+
+def test_lights_parallel_to_axes_and_planes(tmp_path):
+    # Shadow rays with one or two direction components exactly zero, in every combination: each zero pattern has a scan
+    # loop of its own in the wave kernel.
+    p = tmp_path / "parallel_lights.json"
+    p.write_text(PARALLEL_LIGHTS_SCENE)
+    _check_scene(str(p), 224, 136)
+
+
 @pytest.mark.parametrize("k,w,h", [(3, 256, 256), (5, 320, 180)])
 def test_synthetic_icosphere_scene(tmp_path, k, w, h):
     # The benchmark's synthetic mesh (20 * 4**k triangles over the large plane), at sizes the oracle renders in seconds.
