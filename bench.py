@@ -146,6 +146,8 @@ def main():
     stream = streams[0]
     # one uploaded scene per stream: renders of one rt_dscene must not overlap (it owns one set of counters and queues)
     scenes = [ds] + ([rt.DeviceScene(scene, device=local_rank)] if two_deep else [])
+    # frames in flight fill the chip between them: the tiles of every launch go to the dies in strips whatever their number
+    pipeline_flags = rt.RT_RENDER_STRIPS if two_deep else 0
 
     def step(k, flags=0, want_stats=False):
         b = k % len(local)
@@ -155,7 +157,7 @@ def main():
                 pending[b].wait()          # the render stream waits for the gather that last read this tile
                 pending[b] = None
             st = scenes[b % len(scenes)].render_bands_into(local[b].data_ptr(), BAND_ROWS, part_rank, part_world, stream=sk.cuda_stream,
-                                                           flags=flags, want_stats=want_stats)
+                                                           flags=flags | pipeline_flags, want_stats=want_stats)
             if dist_on:
                 pending[b] = dist.gather(local[b], gathered[b] if rank == 0 else None, dst=0, async_op=True)
         return st
@@ -191,7 +193,8 @@ def main():
                 pending[b].wait()
                 pending[b] = None
             ev[k][0].record(sk)
-            scenes[b % len(scenes)].render_bands_into(local[b].data_ptr(), BAND_ROWS, part_rank, part_world, stream=sk.cuda_stream)
+            scenes[b % len(scenes)].render_bands_into(local[b].data_ptr(), BAND_ROWS, part_rank, part_world, stream=sk.cuda_stream,
+                                                      flags=pipeline_flags)
             ev[k][1].record(sk)
             if dist_on:
                 pending[b] = dist.gather(local[b], gathered[b] if rank == 0 else None, dst=0, async_op=True)

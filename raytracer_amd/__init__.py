@@ -24,6 +24,7 @@ RT_RENDER_TIME = 2
 RT_RENDER_LITERAL = 4
 RT_RENDER_STACKED = 8
 RT_RENDER_QUEUED = 16
+RT_RENDER_STRIPS = 32
 
 # Every symbol include/rt_amd.h declares.
 ABI_SYMBOLS = (

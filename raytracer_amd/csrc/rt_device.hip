@@ -193,6 +193,7 @@ static int launch_render(rt_dscene* d, RowMap rows, uint8_t* d_rgb, int32_t* d_i
                          unsigned flags, rt_stats* stats) {
   hipStream_t stream = (hipStream_t)stream_;
   HIP_TRY(hipSetDevice(d->device));
+  rows.strips = (flags & RT_RENDER_STRIPS) ? 1 : 0;
   // the counters are only read back for a caller that passes an rt_stats: no need to clear them for anybody else
   if (stats) HIP_TRY(hipMemsetAsync(d->d_counters, 0, RT_COUNTER_COPIES * RT_COUNTER_STRIDE * sizeof(unsigned long long), stream));
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
@@ -263,7 +264,7 @@ extern "C" int rt_render_rows(rt_dscene* d, int row_begin, int row_end, uint8_t*
   const int H = d->view.cam.height;
   if (row_begin < 0 || row_end > H || row_begin > row_end) { rt_set_error("rt_render_rows: rows outside the image"); return RT_ERR_ARG; }
   const int n = row_end - row_begin;
-  const RowMap rows = {row_begin, n > 0 ? n : 1, 0, n, 0, 0};
+  const RowMap rows = {row_begin, n > 0 ? n : 1, 0, n, 0, 0, 0};
   return launch_render(d, rows, d_rgb, d_ids, d_t, stream, flags, stats);
 }
 
@@ -281,7 +282,7 @@ extern "C" int rt_render_bands(rt_dscene* d, int band_rows, int rank, int nranks
     return RT_ERR_ARG;
   }
   const int mine = rt_band_count(d, band_rows, rank, nranks);
-  const RowMap rows = {rank * band_rows, band_rows, band_rows * nranks, mine * band_rows, 1, 0};
+  const RowMap rows = {rank * band_rows, band_rows, band_rows * nranks, mine * band_rows, 1, 0, 0};
   return launch_render(d, rows, d_rgb_local, d_ids_local, d_t_local, stream, flags, stats);
 }
 

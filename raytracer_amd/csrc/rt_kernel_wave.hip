@@ -1002,10 +1002,12 @@ void rt_launch_wave_kernel(const RtDeviceView& V, const RowMap& rows, bool bounc
   RtWaveArgs A;
   A.tiles_x = grid.x; A.tiles_y = grid.y; A.strips_per_die = 0u;
   static const bool plain_grid = getenv("RT_AMD_PLAIN_GRID") != nullptr;   // measurements
-  // Tiles dealt to the dies in strips: a one-dimensional grid of 8 x strips x rows slots.  Only for launches with many
+  static const uint64_t strip_min_tiles = getenv("RT_AMD_STRIP_MIN_TILES") ? strtoull(getenv("RT_AMD_STRIP_MIN_TILES"), nullptr, 10) : 60000u;
+  // Tiles dealt to the dies in strips: a one-dimensional grid of 8 x strips x rows slots.  Only for launches (60 000 tiles and more) with many
   // times more tiles than the chip holds waves: smaller ones end when their few long waves end, and for those the plain
-  // order is the better one (meshDragon: 1.18 against 1.35 ms at 1920x1080, equal at 2560x1440, 2.88 against 2.70 at 4K).
-  if (!wf.in && RT_WBLOCK == 64 && !plain_grid && (uint64_t)grid.x * grid.y >= 65536u) {
+  // order is the better one (meshDragon: 1.18 against 1.35 ms at 1920x1080, equal at 2560x1440, 2.88 against 2.70 at 4K) -
+  // unless the caller keeps several frames in flight, which fill the chip between them (rows.strips, RT_RENDER_STRIPS).
+  if (!wf.in && RT_WBLOCK == 64 && !plain_grid && ((uint64_t)grid.x * grid.y >= strip_min_tiles || rows.strips)) {
     const uint32_t strips = (grid.x + RT_STRIP_W - 1u) / RT_STRIP_W;
     A.strips_per_die = (strips + RT_DIES - 1u) / RT_DIES;
     grid = dim3(RT_DIES * A.strips_per_die * RT_STRIP_W * grid.y, 1);

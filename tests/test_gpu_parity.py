@@ -193,7 +193,8 @@ def test_two_frames_in_flight_on_two_streams(name):
     torch.cuda.synchronize()
     for k, buf in enumerate(bufs):
         with torch.cuda.stream(streams[k % 2]):
-            scenes[k % 2].render_bands_into(buf.data_ptr(), 16, 0, 1, stream=streams[k % 2].cuda_stream)
+            scenes[k % 2].render_bands_into(buf.data_ptr(), 16, 0, 1, stream=streams[k % 2].cuda_stream,
+                                            flags=rt.RT_RENDER_STRIPS if k >= 2 else 0)   # (tiles dealt to the dies in strips, as the bench asks)
     torch.cuda.synchronize()
     for buf in bufs:
         assert np.array_equal(buf.cpu().numpy(), alone)
