@@ -616,8 +616,11 @@ __device__ __forceinline__ T late_struct(size_t offset) {
 }
 #define LATE_STRUCT(field) late_struct<decltype(RtWaveArgs::field)>(offsetof(RtWaveArgs, field))
 
-template <bool BOUNCE, bool COUNT, bool QUEUES>
-__global__ __launch_bounds__(RT_WBLOCK, BOUNCE ? RT_WAVES_PER_SIMD_BOUNCE : RT_WAVES_PER_SIMD) void render_wave(
+// DENSE (plain variant only): compiled for one more wave per SIMD, at the price of spilled registers in the shading code.
+// It pays for big frames of a heavy mesh, whose walks dominate (meshDragon 4K: 2.71 -> 2.61 ms), not for small frames
+// (1920x1080: 1.24 -> 1.28 ms) nor where shading weighs (sphere scenes: + 50 %); the launch chooses.
+template <bool BOUNCE, bool COUNT, bool QUEUES, bool DENSE = false>
+__global__ __launch_bounds__(RT_WBLOCK, BOUNCE ? RT_WAVES_PER_SIMD_BOUNCE : (DENSE ? RT_WAVES_PER_SIMD + 1 : RT_WAVES_PER_SIMD)) void render_wave(
     const float4* __restrict__ nodes, const float4* __restrict__ tri_leaf, const RtWaveArgs A) {
   const RtSphere* __restrict__ spheres = A.spheres;
   const int n_spheres = A.n_spheres, has_oct = A.has_oct, n_wnodes = A.n_wnodes;
@@ -1022,6 +1025,8 @@ void rt_launch_wave_kernel(const RtDeviceView& V, const RowMap& rows, bool bounc
   else if (bounce && count) LAUNCH(true, true, false);
   else if (bounce) LAUNCH(true, false, false);
   else if (count) LAUNCH(false, true, false);
+  else if ((uint64_t)A.tiles_x * A.tiles_y >= strip_min_tiles && V.has_oct && V.n_wnodes >= 512 && !rows.small)   // a big frame of a big mesh: one more wave per SIMD
+    hipLaunchKernelGGL((render_wave<false, false, false, true>), grid, block, 0, stream, V.wnodes, V.tri_leaf, A);
   else LAUNCH(false, false, false);
 #undef LAUNCH
 }
