@@ -625,8 +625,11 @@ __global__ __launch_bounds__(RT_WBLOCK, BOUNCE ? RT_WAVES_PER_SIMD_BOUNCE : (DEN
   const RtSphere* __restrict__ spheres = A.spheres;
   const int n_spheres = A.n_spheres, has_oct = A.has_oct, n_wnodes = A.n_wnodes;
   auto counters_ptr = [&]() { return LATE(counters_all) + ((blockIdx.x + blockIdx.y) & (RT_COUNTER_COPIES - 1)) * RT_COUNTER_STRIDE; };
-  __shared__ float parked[ShadeState<BOUNCE>::WORDS * RT_WBLOCK];
-  __shared__ uint32_t pack[RT_WBLOCK / 64][48];
+  // LDS of a workgroup: the parked shading state and the lane's three ray counters; the packing area of the epilogue
+  // lies over the same bytes (nothing is parked any more then).  25 words per lane = 6 400 B per wave keeps 24 waves per
+  // compute unit (six per SIMD) within the 160 KB.
+  __shared__ float parked[(ShadeState<BOUNCE>::WORDS + 3) * RT_WBLOCK];
+  uint32_t (*pack)[48] = (uint32_t (*)[48])parked;   // [wave][48]
   const int tid = threadIdx.x, lane = tid & 63;
   float* my_park = &parked[tid];
   WaveStack st = {0u, 0u, 0u, 0u};
@@ -769,10 +772,18 @@ __global__ __launch_bounds__(RT_WBLOCK, BOUNCE ? RT_WAVES_PER_SIMD_BOUNCE : (DEN
       const float stop_t = (phase == PH_SHADOW && !COUNT) ? tr_stop : -1.f;
       if (want) tl.traced++;
       park<BOUNCE>(sh, my_park);
+      {   // the ray counters of the lane wait out the walk in LDS too (else they are spilled around it where registers are short)
+        uint32_t* pk = (uint32_t*)my_park + ShadeState<BOUNCE>::WORDS * RT_WBLOCK;
+        pk[0] = tl.rays; pk[RT_WBLOCK] = tl.shadow; pk[2 * RT_WBLOCK] = tl.traced;
+      }
       asm volatile("" ::: "memory");
       trace_wave<COUNT>(nodes, n_wnodes, tri_leaf, spheres, n_spheres, has_oct != 0, want, tr_e, tr_d, stop_t, h, st, lane, tl);
       asm volatile("" ::: "memory");
       unpark<BOUNCE>(sh, my_park);
+      {
+        const uint32_t* pk = (const uint32_t*)my_park + ShadeState<BOUNCE>::WORDS * RT_WBLOCK;
+        tl.rays = pk[0]; tl.shadow = pk[RT_WBLOCK]; tl.traced = pk[2 * RT_WBLOCK];
+      }
     }
     const rt_kernarg_ptr ka = late_args();   // one opaque copy for the whole shading phase: its loads go out together
     if (phase == PH_CLOSEST) {
