@@ -200,6 +200,56 @@ def test_two_frames_in_flight_on_two_streams(name):
         assert np.array_equal(buf.cpu().numpy(), alone)
 
 
+@pytest.mark.parametrize("name,w,h", [("meshMedBunny", 333, 187), ("lambertBPHSpheres", 130, 75), ("sphere", 5, 3),
+                                      ("meshTorus", 1000, 40), ("meshMedBunny", 8, 600), ("twoSpheres", 264, 16)])
+def test_tile_strips_on_ragged_sizes(name, w, h):
+    # tiles dealt to the dies in strips of four tile columns: widths that leave the last strip, or whole dies, without
+    # tiles (1, 2, 17, 33, 42 and 125 tile columns) must give the bytes of the plain grid, in full frames and in bands
+    ds = rt.DeviceScene(rt.Scene("scenes/%s.json" % name, w, h, 3))
+    rgb, ids, ts, st = ds.render_host()
+    rgb2, ids2, ts2, st2 = ds.render_host(flags=rt.RT_RENDER_STRIPS)
+    assert np.array_equal(rgb2, rgb) and np.array_equal(ids2, ids) and np.array_equal(ts2.view(np.uint32), ts.view(np.uint32))
+    assert st2["rays"] == st["rays"] and st2["rays_traced"] == st["rays_traced"]
+    b0, b1 = h // 3, max(h // 3 + 1, (2 * h) // 3)
+    part, pids, _, _ = ds.render_host(b0, b1, flags=rt.RT_RENDER_STRIPS)
+    assert np.array_equal(part[b0:b1], rgb[b0:b1]) and np.array_equal(pids[b0:b1], ids[b0:b1])
+    assert not part[:b0].any() and not part[b1:].any()
+
+
+_DENSE_CHILD = """
+import hashlib, sys
+import numpy as np
+import raytracer_amd as rt
+for name, w, h in [("meshDragon", 333, 187), ("meshMedBunny", 520, 96), ("meshDragon", 64, 64)]:
+    ds = rt.DeviceScene(rt.Scene("scenes/%s.json" % name, w, h, 3))
+    for flags in (0, rt.RT_RENDER_STRIPS):
+        rgb, ids, ts, st = ds.render_host(flags=flags)
+        print(name, w, h, hashlib.sha256(rgb.tobytes() + ids.tobytes() + ts.tobytes()).hexdigest(), st["rays"], st["rays_traced"])
+"""
+
+
+def test_six_waves_per_simd_variant_on_small_and_ragged_frames():
+    # The variant of the plain kernel compiled for six waves per SIMD is chosen for big frames of big meshes only (the
+    # 4K dragon test runs it); the threshold is read once per process, so a child process with the threshold at one
+    # tile and 8x8 tiles forced renders small ragged frames with it: same bytes, ids, distances and ray counts.
+    import os
+    import subprocess
+    import sys
+    from scenes_common import HERE
+    want = []
+    for name, w, h in [("meshDragon", 333, 187), ("meshMedBunny", 520, 96), ("meshDragon", 64, 64)]:
+        ds = rt.DeviceScene(rt.Scene("scenes/%s.json" % name, w, h, 3))
+        rgb, ids, ts, st = ds.render_host()
+        for _ in range(2):
+            want.append("%s %d %d %s %d %d" % (name, w, h, hashlib.sha256(rgb.tobytes() + ids.tobytes() + ts.tobytes()).hexdigest(),
+                                               st["rays"], st["rays_traced"]))
+    env = dict(os.environ, RT_AMD_STRIP_MIN_TILES="1", RT_AMD_TILE="8")
+    env["PYTHONPATH"] = os.pathsep.join([os.path.join(HERE, ".."), HERE, env.get("PYTHONPATH", "")])
+    out = subprocess.run([sys.executable, "-c", _DENSE_CHILD], env=env, capture_output=True, text=True, timeout=100)
+    assert out.returncode == 0, out.stderr[-2000:]
+    assert out.stdout.strip().splitlines() == want
+
+
 SPOT_SCENE = """{
   "camera": {"fov": 50.0, "position": [0, 6, 14], "up": [0, 1, 0], "target": [0, 1, 0]},
   "objects": [
