@@ -134,18 +134,21 @@ def main():
             os.environ.setdefault(key, val)
     if dist_on and not dist.is_initialized():
         dist.init_process_group("nccl", device_id=dev)
-    # Two frame tiles per rank: the gather of frame k runs on the collective's stream while frame k+1 is rendered.
-    local = [torch.zeros((nb_max * BAND_ROWS, W, 3), dtype=torch.uint8, device=dev) for _ in range(2 if dist_on else 1)]
-    gathered = [[torch.zeros_like(local[0]) for _ in range(world)] for _ in local] if (dist_on and rank == 0) else None
-    pending = [None, None]
-    # With several GPUs a rank's share of a frame is short, and it ends with the few long waves of its silhouette tiles
-    # while most of the chip idles.  So frames are pipelined two deep there: frame k+1 is rendered on a second stream
-    # into the second tile while frame k finishes and is gathered.  One GPU: one stream, launches back to back.
+    # Two or three frame tiles per rank: the gather of frame k runs on the collective's stream while frame k+1 is rendered.
     two_deep = dist_on and os.environ.get("RT_BENCH_ONE_STREAM") != "1"
-    streams = [torch.cuda.current_stream()] + ([torch.cuda.Stream(device=dev)] if two_deep else [])
+    # (three frames in flight from six GPUs on: a share of an eighth of the frame is so short that two of them still end on
+    #  their long waves - 0.45 -> 0.39 ms per frame for the bands of one GPU of 8; no gain for one of 4 or 2, a loss with four)
+    in_flight = max(2, int(os.environ.get("RT_BENCH_IN_FLIGHT", "3" if part_world >= 6 else "2"))) if two_deep else 1
+    local = [torch.zeros((nb_max * BAND_ROWS, W, 3), dtype=torch.uint8, device=dev) for _ in range(max(in_flight, 2) if dist_on else 1)]
+    gathered = [[torch.zeros_like(local[0]) for _ in range(world)] for _ in local] if (dist_on and rank == 0) else None
+    pending = [None] * len(local)
+    # With several GPUs a rank's share of a frame is short, and it ends with the few long waves of its silhouette tiles
+    # while most of the chip idles.  So frames are pipelined two (or three) deep there: frame k+1 is rendered on a second stream
+    # into the second tile while frame k finishes and is gathered.  One GPU: one stream, launches back to back.
+    streams = [torch.cuda.current_stream()] + [torch.cuda.Stream(device=dev) for _ in range(in_flight - 1)]
     stream = streams[0]
     # one uploaded scene per stream: renders of one rt_dscene must not overlap (it owns one set of counters and queues)
-    scenes = [ds] + ([rt.DeviceScene(scene, device=local_rank)] if two_deep else [])
+    scenes = [ds] + [rt.DeviceScene(scene, device=local_rank) for _ in range(in_flight - 1)]
     # frames in flight fill the chip between them: the tiles of every launch go to the dies in strips whatever their number
     pipeline_flags = rt.RT_RENDER_STRIPS if two_deep else 0
 
@@ -259,7 +262,7 @@ def main():
                        "shadow_rays_per_frame": shadow_total, "triangles": info["n_triangles"], "octree_nodes": info["n_nodes"],
                        "partition": ("one GPU renders the whole frame, no exchange" if not dist_on else
                                      "%d-row bands round-robin over %d GPU(s), one RCCL gather per frame%s" % (
-                                         BAND_ROWS, world, ", frames pipelined two deep (the render of frame k+1 overlaps the end and the gather of frame k)"
+                                         BAND_ROWS, world, ", %d frames in flight (the render of frame k+1 overlaps the end and the gather of frame k)" % in_flight
                                          if two_deep else " overlapped with the next frame's render")),
                        "library": rt.version()},
             "roofline": roofline,

@@ -1017,6 +1017,9 @@ void rt_launch_wave_kernel(const RtDeviceView& V, const RowMap& rows, bool bounc
   A.tiles_x = grid.x; A.tiles_y = grid.y; A.strips_per_die = 0u;
   static const bool plain_grid = getenv("RT_AMD_PLAIN_GRID") != nullptr;   // measurements
   static const uint64_t strip_min_tiles = getenv("RT_AMD_STRIP_MIN_TILES") ? strtoull(getenv("RT_AMD_STRIP_MIN_TILES"), nullptr, 10) : 60000u;
+  // (measured with the threshold lowered: meshDragon 1920x1080 1.20 -> 1.27 ms, 2560x1440 1.55 -> 1.56 ms; the bands of one GPU
+  // of 8 / 4 / 2 with two frames in flight 0.47 -> 0.52, 0.75 -> 0.74, 1.36 -> 1.35 ms: the sixth wave only pays on a full frame)
+  static const uint64_t dense_min_tiles = getenv("RT_AMD_DENSE_MIN_TILES") ? strtoull(getenv("RT_AMD_DENSE_MIN_TILES"), nullptr, 10) : strip_min_tiles;
   // Tiles dealt to the dies in strips: a one-dimensional grid of 8 x strips x rows slots.  Only for launches (60 000 tiles and more) with many
   // times more tiles than the chip holds waves: smaller ones end when their few long waves end, and for those the plain
   // order is the better one (meshDragon: 1.18 against 1.35 ms at 1920x1080, equal at 2560x1440, 2.88 against 2.70 at 4K) -
@@ -1036,7 +1039,7 @@ void rt_launch_wave_kernel(const RtDeviceView& V, const RowMap& rows, bool bounc
   else if (bounce && count) LAUNCH(true, true, false);
   else if (bounce) LAUNCH(true, false, false);
   else if (count) LAUNCH(false, true, false);
-  else if ((uint64_t)A.tiles_x * A.tiles_y >= strip_min_tiles && V.has_oct && V.n_wnodes >= 512 && !rows.small)   // a big frame of a big mesh: one more wave per SIMD
+  else if (((uint64_t)A.tiles_x * A.tiles_y >= dense_min_tiles) && V.has_oct && V.n_wnodes >= 512 && !rows.small)   // a big frame of a big mesh: one more wave per SIMD
     hipLaunchKernelGGL((render_wave<false, false, false, true>), grid, block, 0, stream, V.wnodes, V.tri_leaf, A);
   else LAUNCH(false, false, false);
 #undef LAUNCH

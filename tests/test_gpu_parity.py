@@ -243,7 +243,7 @@ def test_six_waves_per_simd_variant_on_small_and_ragged_frames():
         for _ in range(2):
             want.append("%s %d %d %s %d %d" % (name, w, h, hashlib.sha256(rgb.tobytes() + ids.tobytes() + ts.tobytes()).hexdigest(),
                                                st["rays"], st["rays_traced"]))
-    env = dict(os.environ, RT_AMD_STRIP_MIN_TILES="1", RT_AMD_TILE="8")
+    env = dict(os.environ, RT_AMD_DENSE_MIN_TILES="1", RT_AMD_TILE="8")
     env["PYTHONPATH"] = os.pathsep.join([os.path.join(HERE, ".."), HERE, env.get("PYTHONPATH", "")])
     out = subprocess.run([sys.executable, "-c", _DENSE_CHILD], env=env, capture_output=True, text=True, timeout=100)
     assert out.returncode == 0, out.stderr[-2000:]
