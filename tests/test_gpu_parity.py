@@ -216,6 +216,20 @@ def test_tile_strips_on_ragged_sizes(name, w, h):
     assert not part[:b0].any() and not part[b1:].any()
 
 
+@pytest.mark.parametrize("name,w,h", [("sphere", 65535, 3), ("lambertBPHSpheres", 3, 65535), ("meshMedBunny", 65535, 2)])
+def test_longest_image_sides(name, w, h):
+    # the reference's image sides are unsigned shorts: the longest row and the longest column against the oracle, on
+    # the plain grid and with the tiles dealt to the dies in strips (8 192 tile columns, 2 048 strips)
+    o = OracleScene("scenes/%s.json" % name, w, h, 3)
+    orgb, oids, ots, _ = o.render(threads=8)
+    ds = rt.DeviceScene(rt.Scene("scenes/%s.json" % name, w, h, 3))
+    for flags in (0, rt.RT_RENDER_STRIPS):
+        rgb, ids, ts, st = ds.render_host(flags=flags)
+        assert np.array_equal(ids, oids) and np.array_equal(ts.view(np.uint32), ots.view(np.uint32))
+        assert _rgb_close(rgb, orgb)[0] >= 0.999
+        assert st["rays"] >= w * h
+
+
 _DENSE_CHILD = """
 import hashlib, sys
 import numpy as np

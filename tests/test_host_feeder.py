@@ -75,6 +75,11 @@ def test_error_codes(tmp_path):
     with pytest.raises(rt.RtError) as e:
         rt.Scene("scenes/sphere.json", 0, 64, 3)
     assert e.value.status == -1
+    for w, h in ((65536, 4), (4, 65536), (-3, 4)):   # image sides are unsigned shorts in the reference (1..65535)
+        with pytest.raises(rt.RtError) as e:
+            rt.Scene("scenes/sphere.json", w, h, 3)
+        assert e.value.status == -1
+    assert rt.Scene("scenes/sphere.json", 65535, 1, 3).info()["n_spheres"] == 1
     bad = tmp_path / "bad.json"
     bad.write_text('{"camera": {"fov": 45.0, "position": [0,0,5], "up": [0,1,0], "target": [0,0,0]},'
                    ' "objects": [{"__type__": "sphere", "radius": 1, "position": [0,0,0], "materials": ["no_such"]}]}')
