@@ -56,6 +56,18 @@ __device__ __forceinline__ uint32_t uni(uint32_t v) { return __builtin_amdgcn_re
 #define RT_PATHS_ON false
 #endif
 
+// Minimum of a value over the 64 lanes, the same in every lane (all lanes active): quad swaps and row mirrors, then the
+// four rows through scalar registers.
+__device__ __forceinline__ float wave_min(float v) {
+  v = fminf(v, __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xB1, 0xf, 0xf, true)));    // quad_perm [1,0,3,2]
+  v = fminf(v, __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x4E, 0xf, 0xf, true)));    // quad_perm [2,3,0,1]
+  v = fminf(v, __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x141, 0xf, 0xf, true)));   // row_half_mirror
+  v = fminf(v, __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x140, 0xf, 0xf, true)));   // row_mirror
+  const float r0 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 0)), r1 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 16)),
+              r2 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 32)), r3 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 48));
+  return __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, fminf(fminf(r0, r1), fminf(r2, r3)))));
+}
+
 // Closest hit (ray.cu:29-54) for all lanes of the wave at once.
 //   want   : this lane has a ray to trace
 //   stop_t : >= 0 for a shadow ray: the lane drops out as soon as its t falls below stop_t, because
@@ -64,7 +76,7 @@ template <bool COUNT>
 __device__ __forceinline__ void trace_wave(const float4* __restrict__ nodes, int n_wnodes, const float4* __restrict__ tri_leaf,
                                            const RtSphere* __restrict__ spheres, int n_spheres, bool has_oct, bool want,
                                            const RtVec3& e, const RtVec3& d, float stop_t, Hit& hit, WaveStack& st,
-                                           int lane, Tally& tl) {
+                                           int lane, Tally& tl, float* cull_lds) {
   // Lane sets are kept as wave-uniform 64-bit masks in SGPRs (who still has an undecided ray, who entered the
   // current branch, who accepted the current node, ...); they are combined on the scalar unit and only turned
   // back into a per-lane predicate on the rare paths that need one.
@@ -123,6 +135,34 @@ __device__ __forceinline__ void trace_wave(const float4* __restrict__ nodes, int
     // margin that no node of this tree exceeds for this ray (the root's planes bound every node's)
     float neg_eb = 0.f;
     if (presorted) { const float4 ra = rec(cnodes), rb = rec(cnodes + 1); neg_eb = -rt_slab_margin_bound(ra.x, ra.y, ra.z, ra.w, rb.x, rb.y, e, inv, hit.t); }
+#ifdef RT_WAVE_CULL
+    // Measurement build (off in the product; tools/build_variant.sh cull -DRT_WAVE_CULL): the children of a branch are
+    // put in front of the wave's rays as a whole before they are scanned.  On the 4K dragon frame it takes 54 % of the
+    // node iterations away (18.0 M -> 8.3 M) and about 1 % of the time: the iterations it removes are the cheap ones,
+    // whose record was requested an iteration ahead, and each descent now waits for a vector load.
+    // Bounds of the wave's rays (see the descent): per axis the origin that makes a plane distance smallest / largest
+    // and the inverse direction of smallest / largest magnitude.
+    bool cull_on = presorted && !COUNT && (!PATHS || RT_PATHS_ON);
+    if (cull_on) {
+      float cu_eA[3] = {0, 0, 0}, cu_eB[3] = {0, 0, 0}, cu_iS[3] = {0, 0, 0}, cu_iL[3] = {0, 0, 0}, cu_neb = 0.f;
+      const float PINF = __builtin_inff();
+      const float ev[3] = {e.x, e.y, e.z}, iv[3] = {inv.x, inv.y, inv.z};
+      bool finite = true;
+      for (int k = 0; k < 3; k++) {
+        const float emin = wave_min(want ? ev[k] : PINF), emax = -wave_min(want ? -ev[k] : PINF);
+        const float amin = wave_min(want ? fabsf(iv[k]) : PINF), amax = -wave_min(want ? -fabsf(iv[k]) : PINF);
+        const bool neg = ((variant >> k) & 1u) != 0u;
+        cu_iS[k] = neg ? -amin : amin; cu_iL[k] = neg ? -amax : amax;
+        cu_eA[k] = neg ? emin : emax; cu_eB[k] = neg ? emax : emin;
+        finite = finite && amax < PINF;
+      }
+      cu_neb = wave_min(want ? neg_eb : PINF);
+      cull_on = finite && cu_neb > -PINF;
+      // they wait in LDS for the descents (thirteen scalar registers across the walk would be spilled)
+      for (int k = 0; k < 3; k++) { cull_lds[k] = cu_eA[k]; cull_lds[4 + k] = cu_eB[k]; cull_lds[8 + k] = cu_iS[k]; cull_lds[12 + k] = cu_iL[k]; }
+      cull_lds[3] = cu_neb;
+    }
+#endif
     cnode_ptr blk = cnodes + NS * top_first;   // records of the current branch's children
     { const uint32_t c = (uint32_t)__builtin_ctz(rem | 0x100u); nx = rec8(blk + NS * c); }
     // `mine_m` = lanes that entered the current branch and are still undecided.  It only changes when the branch changes or
@@ -408,7 +448,33 @@ __device__ __forceinline__ void trace_wave(const float4* __restrict__ nodes, int
       const uint32_t first = uni(__float_as_uint(nb.z));
       const uint32_t meta = uni(__float_as_uint(nb.w));
       if (meta & 0x80000000u) {   // branch: descend; the parent is only kept if it has children left
-        const uint32_t crem = COUNT ? 0xffu : (meta & 0xffu);
+        uint32_t crem = COUNT ? 0xffu : (meta & 0xffu);
+#ifdef RT_WAVE_CULL
+        if (cull_on) {
+          // Child c in lane c (and in every eighth lane after it): bounds, over all rays of the wave, of the child's
+          // near-plane distances from below and far-plane distances from above, by the lanes' own operations on the
+          // interval ends (rounding is monotone).  If min(span, tF) of those bounds lies below every lane's -Eb, every
+          // lane would reject the child in the scan loop: it is left out of the scan.
+          uint32_t ones = ~0u;
+          asm volatile("" : "+s"(ones));
+          const uint32_t c = __builtin_amdgcn_mbcnt_hi(ones, __builtin_amdgcn_mbcnt_lo(ones, 0u)) & 7u;
+          typedef float f4v __attribute__((ext_vector_type(4)));
+          const f4v* bl = (const f4v*)cull_lds;
+          asm volatile("" : "+v"(bl));   // read here, every time: not carried in registers across the walk
+          const f4v bA = bl[0], bB = bl[1], bS = bl[2], bL = bl[3];
+          const float cu_eA[3] = {bA.x, bA.y, bA.z}, cu_eB[3] = {bB.x, bB.y, bB.z}, cu_iS[3] = {bS.x, bS.y, bS.z}, cu_iL[3] = {bL.x, bL.y, bL.z};
+          const float cu_neb = bA.w;
+          // the children's records by a vector load, eight lanes wide (deriving them from the parent's planes - a child
+          // is a half of the parent per axis, octtree.cu:95-111 - costs a scalar reload and 18 more instructions: slower)
+          const float4 ca = nodes[NS * (first + c)], cb = nodes[NS * (first + c) + 1];   // (near, far) per axis in this variant's copy
+          const float cnx = ca.x, cfx = ca.y, cny = ca.z, cfy = ca.w, cnz = cb.x, cfz = cb.y;
+          const float anx = cnx - cu_eA[0], afx = cfx - cu_eB[0], any_ = cny - cu_eA[1], afy = cfy - cu_eB[1], anz = cnz - cu_eA[2], afz = cfz - cu_eB[2];
+          const float tn = rt_max3(fminf(anx * cu_iS[0], anx * cu_iL[0]), fminf(any_ * cu_iS[1], any_ * cu_iL[1]), fminf(anz * cu_iS[2], anz * cu_iL[2]));
+          const float tf = rt_min3(fmaxf(afx * cu_iS[0], afx * cu_iL[0]), fmaxf(afy * cu_iS[1], afy * cu_iL[1]), fmaxf(afz * cu_iS[2], afz * cu_iL[2]));
+          const float bound = fminf(tf - tn, tf);
+          crem &= ~((uint32_t)__builtin_amdgcn_ballot_w64(bound < cu_neb) & 0xffu);
+        }
+#endif
         if (crem == 0u) continue;
         if (rem != 0u) {
           // lane sp keeps entry sp.  The lane number is counted afresh here (two instructions on an opaque mask) rather
@@ -632,6 +698,7 @@ __global__ __launch_bounds__(RT_WBLOCK, BOUNCE ? RT_WAVES_PER_SIMD_BOUNCE : (DEN
   uint32_t (*pack)[48] = (uint32_t (*)[48])parked;   // [wave][48]
   const int tid = threadIdx.x, lane = tid & 63;
   float* my_park = &parked[tid];
+  __shared__ float cull_sh[16 * (RT_WBLOCK / 64)];   // bounds of the wave's rays during a walk (trace_wave)
   WaveStack st = {0u, 0u, 0u, 0u};
   // Pixel of a thread: wave w of the block owns the 8x8 tile (w % RT_WAVES_X, w / RT_WAVES_X) of the block's pixels.  The
   // coordinates are needed at the start, after the primary ray and at the end; they are derived again each time
@@ -777,7 +844,7 @@ __global__ __launch_bounds__(RT_WBLOCK, BOUNCE ? RT_WAVES_PER_SIMD_BOUNCE : (DEN
         pk[0] = tl.rays; pk[RT_WBLOCK] = tl.shadow; pk[2 * RT_WBLOCK] = tl.traced;
       }
       asm volatile("" ::: "memory");
-      trace_wave<COUNT>(nodes, n_wnodes, tri_leaf, spheres, n_spheres, has_oct != 0, want, tr_e, tr_d, stop_t, h, st, lane, tl);
+      trace_wave<COUNT>(nodes, n_wnodes, tri_leaf, spheres, n_spheres, has_oct != 0, want, tr_e, tr_d, stop_t, h, st, lane, tl, cull_sh + 16 * (tid >> 6));
       asm volatile("" ::: "memory");
       unpark<BOUNCE>(sh, my_park);
       {
