@@ -663,7 +663,7 @@ struct RtWaveArgs {
   uint8_t* rgb; int32_t* ids; float* ts; unsigned long long* counters_all; int tally;
   // Tiles of the launch and how they are dealt to the chip's dies (see tile_of): tiles per row / column, strips of
   // RT_STRIP_W tile columns per die (0: a plain two-dimensional grid, one workgroup per tile)
-  uint32_t tiles_x, tiles_y, strips_per_die;
+  uint32_t tiles_x, tiles_y, strips_per_die, centre_first;
   RtQueues wf;
 };
 #define RT_WAVE_ARGS_OFFSET 16   // two pointers in front of the block
@@ -714,8 +714,11 @@ __global__ __launch_bounds__(RT_WBLOCK, BOUNCE ? RT_WAVES_PER_SIMD_BOUNCE : (DEN
   // Tile of this workgroup.  Workgroups go to the eight dies (XCDs) of the chip in turn, each die with its own L2: so
   // that a die keeps meeting the same part of the scene, workgroup i renders a tile of die i % 8's own strips - strips of
   // RT_STRIP_W tile columns, dealt to the dies round-robin across the picture (balanced, yet each die sees an eighth of
-  // it) - one strip after the other, each from the top down.  A slot beyond the picture (ragged widths) has no tile:
-  // its lanes are invalid.  (Measured on the headline frame: 2.88 ms with a plain grid, 2.72 ms with the strips walked
+  // it) - one strip after the other, each from the top down, beginning with the die's strip nearest the middle of the
+  // picture and going outwards on alternating sides: what is looked at tends to sit in the middle, its tiles hold the
+  // longest waves, and a long wave that starts late is what the end of the launch waits for (headline frame: the longest
+  // wave, 0.94 ms, started at 1.84 of 2.87 ms with the strips walked left to right; 2.56 -> 2.50-2.52 ms).  A slot beyond
+  // the picture (ragged widths) has no tile: its lanes are invalid.  (Measured on the headline frame: 2.88 ms with a plain grid, 2.72 ms with the strips walked
   // row by row, 2.70 ms strip by strip; strips 2 or 8 columns wide and square blocks of 4 to 16 tiles: 2.71 to 2.84 ms.)
   struct Tile { uint32_t x, y; };
   auto tile_of = [&]() {
@@ -723,7 +726,9 @@ __global__ __launch_bounds__(RT_WBLOCK, BOUNCE ? RT_WAVES_PER_SIMD_BOUNCE : (DEN
     const uint32_t spd = LATE(strips_per_die);
     if (spd != 0u) {
       const uint32_t die = blockIdx.x % RT_DIES, j = blockIdx.x / RT_DIES;
-      const uint32_t per_strip = RT_STRIP_W * LATE(tiles_y), strip = j / per_strip, in_strip = j % per_strip;
+      const uint32_t per_strip = RT_STRIP_W * LATE(tiles_y), in_strip = j % per_strip;
+      uint32_t strip = j / per_strip;
+      if (LATE(centre_first)) { const uint32_t off = (strip + 1u) >> 1; strip = (strip & 1u) ? (spd >> 1) - off : (spd >> 1) + off; }
       t.y = in_strip / RT_STRIP_W;
       t.x = (strip * RT_DIES + die) * RT_STRIP_W + in_strip % RT_STRIP_W;
     }
@@ -1089,6 +1094,8 @@ void rt_launch_wave_kernel(const RtDeviceView& V, const RowMap& rows, bool bounc
   }
   RtWaveArgs A;
   A.tiles_x = grid.x; A.tiles_y = grid.y; A.strips_per_die = 0u;
+  static const bool strips_in_order = getenv("RT_AMD_STRIPS_IN_ORDER") != nullptr;   // measurements
+  A.centre_first = strips_in_order ? 0u : 1u;
   static const bool plain_grid = getenv("RT_AMD_PLAIN_GRID") != nullptr;   // measurements
   static const uint64_t strip_min_tiles = getenv("RT_AMD_STRIP_MIN_TILES") ? strtoull(getenv("RT_AMD_STRIP_MIN_TILES"), nullptr, 10) : 60000u;
   // (measured with the threshold lowered: meshDragon 1920x1080 1.20 -> 1.27 ms, 2560x1440 1.55 -> 1.56 ms; the bands of one GPU
