@@ -717,7 +717,7 @@ __global__ __launch_bounds__(RT_WBLOCK, BOUNCE ? RT_WAVES_PER_SIMD_BOUNCE : (DEN
   // it) - one strip after the other, each from the top down, beginning with the die's strip nearest the middle of the
   // picture and going outwards on alternating sides: what is looked at tends to sit in the middle, its tiles hold the
   // longest waves, and a long wave that starts late is what the end of the launch waits for (headline frame: the longest
-  // wave, 0.94 ms, started at 1.84 of 2.87 ms with the strips walked left to right; 2.56 -> 2.50-2.52 ms).  A slot beyond
+  // wave, 0.94 ms, started at 1.84 of 2.87 ms with the strips walked left to right; 2.56 -> 2.50-2.52 ms; the rows of a plain grid taken the same way: 4 % less at 1280x720, nothing at 1920x1080, slower at 512x512).  A slot beyond
   // the picture (ragged widths) has no tile: its lanes are invalid.  (Measured on the headline frame: 2.88 ms with a plain grid, 2.72 ms with the strips walked
   // row by row, 2.70 ms strip by strip; strips 2 or 8 columns wide and square blocks of 4 to 16 tiles: 2.71 to 2.84 ms.)
   struct Tile { uint32_t x, y; };
