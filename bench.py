@@ -235,7 +235,7 @@ def main():
             counts_from = "instrumented kernel variant"
         roofline = None
         if ref and ref["rays"] == rays_total:
-            flop = ref["node_tests"] * F_NODE + ref["tri_tests"] * F_TRI + ref["sphere_tests"] * F_SPH + ref["rays"] * F_SHADE
+            flop = ref["node_tests"] * F_NODE + ref["tri_tests"] * F_TRI + ref.get("sphere_tests", 0) * F_SPH + ref["rays"] * F_SHADE
             byts = ref["node_tests"] * B_NODE + ref["tri_tests"] * B_TRI + ref["rays"] * B_RAY
             # per launch: this rank's share of the frame over the launch's own duration; with frames pipelined two deep
             # two launches share the GPU and their durations overlap, so the rate is taken over the time per frame then

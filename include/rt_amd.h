@@ -79,7 +79,7 @@ enum {
   RT_RENDER_STACKED = 8,
   RT_RENDER_QUEUED = 16,
   /* Deal the tiles of the launch to the chip's dies in strips whatever their number (the library does so by itself from
-   * 60 000 tiles on).  For callers that keep several frames or bands in flight on different streams: together those fill
+   * 4 000 tiles on).  For callers that keep several frames or bands in flight on different streams: together those fill
    * the chip, and each die's L2 then keeps meeting its own part of the scene.  A single small launch is slower this way. */
   RT_RENDER_STRIPS = 32
 };

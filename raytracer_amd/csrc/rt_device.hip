@@ -58,7 +58,7 @@ int upload(rt_dscene* d, const std::vector<T>& v, const void** out) {
 
 }  // namespace
 
-extern "C" const char* rt_version(void) { return "rt_amd 1.4 gfx950 (wave-synchronous traversal, exact division-free predicates)"; }
+extern "C" const char* rt_version(void) { return "rt_amd 1.5 gfx950 (wave-synchronous traversal, exact division-free predicates)"; }
 
 extern "C" void rt_dscene_destroy(rt_dscene* d) {
   if (!d) return;

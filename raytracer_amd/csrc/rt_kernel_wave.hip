@@ -1097,14 +1097,16 @@ void rt_launch_wave_kernel(const RtDeviceView& V, const RowMap& rows, bool bounc
   static const bool strips_in_order = getenv("RT_AMD_STRIPS_IN_ORDER") != nullptr;   // measurements
   A.centre_first = strips_in_order ? 0u : 1u;
   static const bool plain_grid = getenv("RT_AMD_PLAIN_GRID") != nullptr;   // measurements
-  static const uint64_t strip_min_tiles = getenv("RT_AMD_STRIP_MIN_TILES") ? strtoull(getenv("RT_AMD_STRIP_MIN_TILES"), nullptr, 10) : 60000u;
+  static const uint64_t strip_min_tiles = getenv("RT_AMD_STRIP_MIN_TILES") ? strtoull(getenv("RT_AMD_STRIP_MIN_TILES"), nullptr, 10) : 4000u;
   // (measured with the threshold lowered: meshDragon 1920x1080 1.20 -> 1.27 ms, 2560x1440 1.55 -> 1.56 ms; the bands of one GPU
   // of 8 / 4 / 2 with two frames in flight 0.47 -> 0.52, 0.75 -> 0.74, 1.36 -> 1.35 ms: the sixth wave only pays on a full frame)
-  static const uint64_t dense_min_tiles = getenv("RT_AMD_DENSE_MIN_TILES") ? strtoull(getenv("RT_AMD_DENSE_MIN_TILES"), nullptr, 10) : strip_min_tiles;
-  // Tiles dealt to the dies in strips: a one-dimensional grid of 8 x strips x rows slots.  Only for launches (60 000 tiles and more) with many
-  // times more tiles than the chip holds waves: smaller ones end when their few long waves end, and for those the plain
-  // order is the better one (meshDragon: 1.18 against 1.35 ms at 1920x1080, equal at 2560x1440, 2.88 against 2.70 at 4K) -
-  // unless the caller keeps several frames in flight, which fill the chip between them (rows.strips, RT_RENDER_STRIPS).
+  static const uint64_t dense_min_tiles = getenv("RT_AMD_DENSE_MIN_TILES") ? strtoull(getenv("RT_AMD_DENSE_MIN_TILES"), nullptr, 10) : 60000u;
+  // Tiles dealt to the dies in strips: a one-dimensional grid of 8 x strips x rows slots, for launches of 4 000 tiles or
+  // more, or on request (rows.strips, RT_RENDER_STRIPS).  Since each die walks its strips from the middle outwards the
+  // strips pay from about 1024x768 on, mostly through that order: a small frame ends when its few long waves end, and
+  // those now start first (meshDragon 1024x768 1.23 -> 0.98 ms, 1600x900 1.18 -> 0.92, 1920x1080 1.22 -> 1.11, 2560x1440
+  // 1.55 -> 1.35; meshTorus 1280x720 1.00 -> 0.90; lambertBPHSpheres 1920x1080 0.30 -> 0.27; meshMedBunny within 5 % either
+  // way).  With the strips walked left to right they only paid from 60 000 tiles on.
   if (!wf.in && RT_WBLOCK == 64 && !plain_grid && ((uint64_t)grid.x * grid.y >= strip_min_tiles || rows.strips)) {
     const uint32_t strips = (grid.x + RT_STRIP_W - 1u) / RT_STRIP_W;
     A.strips_per_die = (strips + RT_DIES - 1u) / RT_DIES;
