@@ -67,6 +67,7 @@ typedef struct rt_stats {
    * of which boundary compare form, triangle iterations, reaching stage 2, stage 3, the quotient stage */
   uint64_t wave_paths[8];
   float kernel_ms;   /* HIP-event time of the render kernels of this call (0 unless RT_RENDER_TIME) */
+  float copy_ms;     /* rt_render_rows_host with RT_RENDER_TIME: the copy of the rows to host memory (main.cu:56-57) */
 } rt_stats;
 
 enum {
@@ -110,6 +111,11 @@ int rt_scene_dump_camera(const rt_scene* s, float* out19);
  * instead of one cudaMalloc per object). */
 int rt_scene_upload(const rt_scene* s, int device, rt_dscene** out);
 void rt_dscene_destroy(rt_dscene* d);
+/* Another render context on the scene arrays `d` already holds in HBM: its own counters, queue buffers and host-path
+ * buffers, nothing uploaded again.  For callers that keep several frames (or bands) in flight on different streams;
+ * the scene arrays are freed when the last handle on them is destroyed, in any order.  The reference renders one
+ * frame per process (main.cu:14-70) and has nothing of the kind. */
+int rt_dscene_fork(const rt_dscene* d, rt_dscene** out);
 
 /* Render image rows [row_begin,row_end) (row 0 = top).  Replaces the film
  * launch + cudaDeviceSynchronize (main.cu:38-54).
@@ -121,7 +127,8 @@ void rt_dscene_destroy(rt_dscene* d);
  *           read back, which synchronises the stream) or the scene's bounce
  *           rays go through queues (RT_RENDER_QUEUED; queue fills are read back).
  * An rt_dscene owns one set of counters and queue buffers: calls on the same
- * rt_dscene must not overlap (use one rt_dscene per stream that renders concurrently). */
+ * rt_dscene must not overlap (rt_dscene_fork gives each concurrent stream a handle of its own).
+ * Every entry point leaves the calling thread's current HIP device as it found it. */
 int rt_render_rows(rt_dscene* d, int row_begin, int row_end, uint8_t* d_rgb, int32_t* d_ids, float* d_t,
                    void* stream, unsigned flags, rt_stats* stats);
 
@@ -136,9 +143,45 @@ int rt_band_count(const rt_dscene* d, int band_rows, int rank, int nranks);
 int rt_render_bands(rt_dscene* d, int band_rows, int rank, int nranks, uint8_t* d_rgb_local, int32_t* d_ids_local,
                     float* d_t_local, void* stream, unsigned flags, rt_stats* stats);
 
-/* Same as rt_render_rows, into HOST memory (adds the device->host copy of main.cu:56-57). */
+/* ---- several GPUs: the one exchange step (RCCL over xGMI) ----------------------------------------------------------
+ * The reference has no multi-GPU path; its single device->host step is the cudaMemcpy of main.cu:56-57.  Here rank r of
+ * n renders its bands packed (rt_render_bands) and ONE gather of the equal-sized tiles puts them on rank 0, where
+ * rt_unpack_bands restores image order.  RCCL is loaded on first use (librccl.so.1), never by single-GPU callers.
+ * An rt_comm is one rank of a communicator: either one process per GPU (rank 0 makes an id with rt_comm_unique_id,
+ * hands its 128 bytes to the others by any means, everybody calls rt_comm_init_rank), or one process driving n devices
+ * (rt_comm_init_all fills out[0..n-1]; calls for several ranks from one thread go between rt_comm_group_begin / _end). */
+typedef struct rt_comm rt_comm;
+#define RT_COMM_ID_BYTES 128
+int rt_comm_unique_id(void* id128);
+int rt_comm_init_rank(const void* id128, int nranks, int rank, int device, rt_comm** out);
+int rt_comm_init_all(int ndev, const int* devices, rt_comm** out);
+void rt_comm_destroy(rt_comm* c);
+int rt_comm_group_begin(void);
+int rt_comm_group_end(void);
+/* d_local: this rank's tile (bytes_per_rank bytes, the same on every rank: rank 0 owns the most bands);
+ * d_gathered: on rank 0, nranks * bytes_per_rank bytes, tile k at k * bytes_per_rank (ignored elsewhere).
+ * Asynchronous on `stream`, ordered behind the render that was enqueued on it. */
+int rt_gather_bands(rt_comm* c, const uint8_t* d_local, size_t bytes_per_rank, uint8_t* d_gathered, void* stream);
+/* Rank 0: the gathered tiles back into image order (width * height * bytes_per_pixel bytes; 3 for RGB, 4 for ids or t). */
+int rt_unpack_bands(const uint8_t* d_gathered, size_t bytes_per_rank, int nranks, int band_rows, int width, int height,
+                    int bytes_per_pixel, uint8_t* d_image, void* stream);
+/* One frame on the n devices of one process (`run --gpus n`): scenes[r] / comms[r] = rank r, the same scene uploaded to
+ * each device.  Renders, gathers, unpacks on scenes[0]'s device and copies the frame to h_rgb.  stats (optional): counters
+ * summed over the devices; kernel_ms = first launch to last tile in place on the first device, copy_ms = the copy out. */
+int rt_render_frame_gathered(rt_dscene* const* scenes, rt_comm* const* comms, int n, int band_rows, uint8_t* h_rgb,
+                             unsigned flags, rt_stats* stats);
+/* Size, counts and device of an uploaded scene (device may be NULL). */
+int rt_dscene_get_info(const rt_dscene* d, rt_scene_info* out, int* device);
+
+/* Same as rt_render_rows, into HOST memory (adds the device->host copy of main.cu:56-57).  The device frame buffers
+ * and a pinned staging buffer are kept by the rt_dscene from call to call.  Destinations in pinned memory
+ * (rt_host_alloc) are written by the copy engine directly; pageable ones are filled in slices through the staging
+ * buffer.  Synchronous. */
 int rt_render_rows_host(rt_dscene* d, int row_begin, int row_end, uint8_t* h_rgb, int32_t* h_ids, float* h_t,
                         unsigned flags, rt_stats* stats);
+/* Page-locked host memory for the outputs of rt_render_rows_host (replaces the malloc of main.cu:41-42). */
+void* rt_host_alloc(size_t bytes);
+void rt_host_free(void* p);
 
 /* 8-bit RGB PNG writer.  Replaces write_image (display/display.cpp:7-16). */
 int rt_write_png(const char* path, int width, int height, const uint8_t* rgb);

@@ -29,8 +29,10 @@ RT_RENDER_STRIPS = 32
 # Every symbol include/rt_amd.h declares.
 ABI_SYMBOLS = (
     "rt_scene_load", "rt_scene_destroy", "rt_scene_get_info", "rt_scene_dump_tree", "rt_scene_dump_triangles",
-    "rt_scene_dump_camera", "rt_scene_upload", "rt_dscene_destroy", "rt_render_rows", "rt_render_rows_host",
-    "rt_band_count", "rt_render_bands",
+    "rt_scene_dump_camera", "rt_scene_upload", "rt_dscene_destroy", "rt_dscene_fork", "rt_render_rows", "rt_render_rows_host",
+    "rt_host_alloc", "rt_host_free", "rt_band_count", "rt_render_bands", "rt_dscene_get_info",
+    "rt_comm_unique_id", "rt_comm_init_rank", "rt_comm_init_all", "rt_comm_destroy", "rt_comm_group_begin", "rt_comm_group_end",
+    "rt_gather_bands", "rt_unpack_bands", "rt_render_frame_gathered",
     "rt_write_png", "rt_strerror", "rt_last_error", "rt_version",
 )
 
@@ -54,7 +56,7 @@ class SceneInfo(C.Structure):
 class Stats(C.Structure):
     _fields_ = [(n, C.c_uint64) for n in (
         "rays", "shadow_rays", "node_tests", "leaf_visits", "tri_tests", "sphere_tests", "ub_leave_level0",
-        "ub_level_overflow", "ub_stack_overflow", "rays_traced")] + [("wave_paths", C.c_uint64 * 8), ("kernel_ms", C.c_float)]
+        "ub_level_overflow", "ub_stack_overflow", "rays_traced")] + [("wave_paths", C.c_uint64 * 8), ("kernel_ms", C.c_float), ("copy_ms", C.c_float)]
 
     def as_dict(self):
         d = {n: getattr(self, n) for n, _ in self._fields_ if n != "wave_paths"}
@@ -100,6 +102,11 @@ def lib():
         L.rt_scene_upload.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_void_p)]
         L.rt_dscene_destroy.argtypes = [C.c_void_p]
         L.rt_dscene_destroy.restype = None
+        L.rt_dscene_fork.argtypes = [C.c_void_p, C.POINTER(C.c_void_p)]
+        L.rt_host_alloc.argtypes = [C.c_size_t]
+        L.rt_host_alloc.restype = C.c_void_p
+        L.rt_host_free.argtypes = [C.c_void_p]
+        L.rt_host_free.restype = None
         L.rt_render_rows.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                      C.c_uint, C.POINTER(Stats)]
         L.rt_render_rows_host.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint,
@@ -107,6 +114,16 @@ def lib():
         L.rt_band_count.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int]
         L.rt_render_bands.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                       C.c_uint, C.POINTER(Stats)]
+        L.rt_dscene_get_info.argtypes = [C.c_void_p, C.POINTER(SceneInfo), C.POINTER(C.c_int)]
+        L.rt_comm_unique_id.argtypes = [C.c_void_p]
+        L.rt_comm_init_rank.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_void_p)]
+        L.rt_comm_init_all.argtypes = [C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_void_p)]
+        L.rt_comm_destroy.argtypes = [C.c_void_p]
+        L.rt_comm_destroy.restype = None
+        L.rt_gather_bands.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p]
+        L.rt_unpack_bands.argtypes = [C.c_void_p, C.c_size_t, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]
+        L.rt_render_frame_gathered.argtypes = [C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.c_int, C.c_int, C.c_void_p, C.c_uint,
+                                               C.POINTER(Stats)]
         L.rt_write_png.argtypes = [C.c_char_p, C.c_int, C.c_int, C.c_void_p]
         L.rt_strerror.argtypes = [C.c_int]
         L.rt_strerror.restype = C.c_char_p
@@ -180,12 +197,19 @@ class Scene:
 class DeviceScene:
     """A Scene resident in one GPU's HBM (rt_dscene)."""
 
-    def __init__(self, scene, device=0):
+    def __init__(self, scene, device=0, _fork_of=None):
         self.h = C.c_void_p()
         self.scene = scene
         self.device = device
         self.width, self.height = scene.width, scene.height
-        _check(lib().rt_scene_upload(scene.h, device, C.byref(self.h)))
+        if _fork_of is not None:
+            _check(lib().rt_dscene_fork(_fork_of.h, C.byref(self.h)))
+        else:
+            _check(lib().rt_scene_upload(scene.h, device, C.byref(self.h)))
+
+    def fork(self):
+        """Another render context (counters, queues) on the same uploaded scene: one per stream that renders concurrently."""
+        return DeviceScene(self.scene, self.device, _fork_of=self)
 
     def close(self):
         if getattr(self, "h", None):
@@ -229,6 +253,62 @@ class DeviceScene:
         _check(lib().rt_render_bands(self.h, band_rows, rank, nranks, rgb_ptr, ids_ptr, t_ptr, stream, flags,
                                      C.byref(st) if want_stats else None))
         return st.as_dict() if want_stats else None
+
+
+COMM_ID_BYTES = 128
+
+
+def comm_unique_id():
+    """128 bytes that rank 0 makes and every rank of a communicator needs (send them over any channel)."""
+    buf = C.create_string_buffer(COMM_ID_BYTES)
+    _check(lib().rt_comm_unique_id(buf))
+    return buf.raw
+
+
+class Comm:
+    """One rank of an RCCL communicator (rt_comm): the framebuffer gather of a frame rendered on several GPUs."""
+
+    def __init__(self, handle, rank, nranks):
+        self.h, self.rank, self.nranks = handle, rank, nranks
+
+    @classmethod
+    def init_rank(cls, unique_id, nranks, rank, device):
+        h = C.c_void_p()
+        _check(lib().rt_comm_init_rank(unique_id, nranks, rank, device, C.byref(h)))
+        return cls(h, rank, nranks)
+
+    @classmethod
+    def init_all(cls, devices):
+        n = len(devices)
+        hs = (C.c_void_p * n)()
+        _check(lib().rt_comm_init_all(n, (C.c_int * n)(*devices), hs))
+        return [cls(C.c_void_p(hs[i]), i, n) for i in range(n)]
+
+    def gather_bands(self, local_ptr, bytes_per_rank, gathered_ptr, stream=None):
+        _check(lib().rt_gather_bands(self.h, local_ptr, bytes_per_rank, gathered_ptr, stream))
+
+    def close(self):
+        if getattr(self, "h", None):
+            lib().rt_comm_destroy(self.h)
+            self.h = None
+
+    __del__ = close
+
+
+def unpack_bands(gathered_ptr, bytes_per_rank, nranks, band_rows, width, height, bytes_per_pixel, image_ptr, stream=None):
+    """Rank 0, on the device: the gathered packed tiles back into image order."""
+    _check(lib().rt_unpack_bands(gathered_ptr, bytes_per_rank, nranks, band_rows, width, height, bytes_per_pixel, image_ptr, stream))
+
+
+def render_frame_gathered(dscenes, comms, band_rows=16, flags=0):
+    """One frame on the devices of `dscenes` (one process): bands, one RCCL gather, the frame in host memory."""
+    n = len(dscenes)
+    w, h = dscenes[0].width, dscenes[0].height
+    rgb = np.zeros((h, w, 3), np.uint8)
+    st = Stats()
+    _check(lib().rt_render_frame_gathered((C.c_void_p * n)(*[d.h.value for d in dscenes]), (C.c_void_p * n)(*[c.h.value for c in comms]),
+                                          n, band_rows, rgb.ctypes.data, flags, C.byref(st)))
+    return rgb, st.as_dict()
 
 
 def band_rows_of(height, band_rows, rank, nranks):

@@ -5,7 +5,12 @@
 // flags may appear anywhere and are matched exactly; without -s the usage text is printed and the
 // exit status is 0; the banner of defaults, "Oct taken seconds: x" and "Rendering seconds: y" go to
 // stdout; mesh paths inside the scene are relative to the working directory.
-// Additions (do not change the above): --device N, --stats (one JSON line with ray counts and rates).
+// Additions (do not change the above):
+//   --device N      HIP device of a single-GPU render (default 0)
+//   --gpus N        render the frame on devices 0..N-1 of this node: 16-row bands dealt round-robin, one RCCL gather
+//   --stats         one JSON line: ray counts, time per phase (parse, octree, upload, kernel, copy, png), Mrays/s and the
+//                   fraction of the FP32 vector roofline (from one more, instrumented, launch outside the timed part)
+//   --dump-ids F    primary-hit primitive ids, W*H little-endian int32 in row order (triangle >= 0, sphere s = -2-s, miss = -1)
 #include <chrono>
 #include <cstdio>
 #include <cstdlib>
@@ -28,13 +33,14 @@ static bool has_option(int ac, char** av, const char* name) {
 
 int main(int ac, char** av) {
   using clk = std::chrono::steady_clock;
+  auto seconds_since = [](clk::time_point t) { return std::chrono::duration<double>(clk::now() - t).count(); };
   auto t0 = clk::now();
   if (ac < 2 || !has_option(ac, av, "-s") || !option_value(ac, av, "-s")) {
     printf("Usage: ./raytracer -w W -h H -s scene.json ");
     printf("-r resources.txt -i image.png");
     return 0;
   }
-  int W = 512, H = 512, depth = 3, device = 0;
+  int W = 512, H = 512, depth = 3, device = 0, gpus = 0;
   std::string res = "resources.json", img = "image.png", banner = "Using following defaults:\n";
   if (option_value(ac, av, "-w")) W = atoi(option_value(ac, av, "-w")); else banner += "+ Width: 512\n";
   if (option_value(ac, av, "-h")) H = atoi(option_value(ac, av, "-h")); else banner += "+ Height: 512\n";
@@ -42,8 +48,12 @@ int main(int ac, char** av) {
   if (option_value(ac, av, "-r")) res = option_value(ac, av, "-r"); else banner += "+ Resources: resources.json\n";
   if (option_value(ac, av, "-i")) img = option_value(ac, av, "-i"); else banner += "+ Image: image.png\n";
   if (option_value(ac, av, "--device")) device = atoi(option_value(ac, av, "--device"));
+  if (option_value(ac, av, "--gpus")) gpus = atoi(option_value(ac, av, "--gpus"));
   const bool want_stats = has_option(ac, av, "--stats");
+  const char* ids_path = option_value(ac, av, "--dump-ids");
   printf("%s", banner.c_str());
+  if (gpus < 0 || gpus > 64) { fprintf(stderr, "run: --gpus must be 1..64\n"); return 1; }
+  if (gpus > 0 && ids_path) { fprintf(stderr, "run: --dump-ids is a single-GPU option\n"); return 1; }
 
   rt_scene* sc = nullptr;
   int rc = rt_scene_load(option_value(ac, av, "-s"), res.c_str(), "", W, H, depth, &sc);
@@ -52,28 +62,64 @@ int main(int ac, char** av) {
     printf("%s\n", rt_last_error());
     return 1;
   }
-  rt_dscene* ds = nullptr;
-  rc = rt_scene_upload(sc, device, &ds);
-  if (rc != RT_OK) { fprintf(stderr, "run: %s\n", rt_last_error()); return 1; }
-  printf("Oct taken seconds: %g\n", std::chrono::duration<double>(clk::now() - t0).count());
+  rt_scene_info info;
+  rt_scene_get_info(sc, &info);
+  const auto t_up = clk::now();
+  const int n_dev = gpus > 0 ? gpus : 1;
+  std::vector<rt_dscene*> ds(n_dev, nullptr);
+  std::vector<rt_comm*> comms(n_dev, nullptr);
+  std::vector<int> devs(n_dev);
+  for (int r = 0; r < n_dev; r++) {
+    devs[r] = gpus > 0 ? r : device;
+    rc = rt_scene_upload(sc, devs[r], &ds[r]);
+    if (rc != RT_OK) { fprintf(stderr, "run: %s\n", rt_last_error()); return 1; }
+  }
+  if (gpus > 0 && (rc = rt_comm_init_all(n_dev, devs.data(), comms.data())) != RT_OK) { fprintf(stderr, "run: %s\n", rt_last_error()); return 1; }
+  const double upload_s = seconds_since(t_up);
+  printf("Oct taken seconds: %g\n", seconds_since(t0));
   t0 = clk::now();
 
-  std::vector<uint8_t> rgb((size_t)W * H * 3);
-  rt_stats st;
-  rc = rt_render_rows_host(ds, 0, H, rgb.data(), nullptr, nullptr, RT_RENDER_TIME, &st);
-  if (rc != RT_OK) printf("kernel launch failed with error \"%s\".\n", rt_last_error());   // main.cu:51-54: report, carry on
-  rc = rt_write_png(img.c_str(), W, H, rgb.data());
-  if (rc != RT_OK) fprintf(stderr, "run: %s\n", rt_last_error());
-  rt_dscene_destroy(ds);
+  // page-locked, so that the copy engine writes the frame straight into it
+  const size_t px = (size_t)W * H;
+  uint8_t* rgb = (uint8_t*)rt_host_alloc(px * 3);
+  int32_t* ids = ids_path ? (int32_t*)rt_host_alloc(px * 4) : nullptr;
+  if (!rgb || (ids_path && !ids)) { fprintf(stderr, "run: %s\n", rt_last_error()); return 1; }
+  memset(rgb, 0, px * 3);
+  rt_stats st = {};
+  if (gpus > 0) rc = rt_render_frame_gathered(ds.data(), comms.data(), n_dev, 16, rgb, 0, &st);
+  else rc = rt_render_rows_host(ds[0], 0, H, rgb, ids, nullptr, RT_RENDER_TIME, &st);
+  const bool rendered = rc == RT_OK;
+  if (!rendered) printf("kernel launch failed with error \"%s\".\n", rt_last_error());   // main.cu:51-54: report, carry on
+  int status = 0;
+  const auto t_png = clk::now();
+  rc = rt_write_png(img.c_str(), W, H, rgb);
+  if (rc != RT_OK) { fprintf(stderr, "run: %s\n", rt_last_error()); status = 1; }
+  const double png_s = seconds_since(t_png);
+  if (ids_path && rendered) {
+    FILE* f = fopen(ids_path, "wb");
+    if (!f || fwrite(ids, 4, px, f) != px) { fprintf(stderr, "run: cannot write %s\n", ids_path); status = 1; }
+    if (f) fclose(f);
+  }
+  // the roofline figure of --stats needs the test counts of the frame: one instrumented launch, outside "Rendering seconds"
+  rt_stats counted = {};
+  const double render_s = seconds_since(t0);
+  if (want_stats && rendered && rt_render_rows_host(ds[0], 0, H, rgb, nullptr, nullptr, RT_RENDER_COUNT_TESTS, &counted) != RT_OK) counted = rt_stats{};
+  for (int r = 0; r < n_dev; r++) { rt_comm_destroy(comms[r]); rt_dscene_destroy(ds[r]); }
   rt_scene_destroy(sc);
-  const double render_s = std::chrono::duration<double>(clk::now() - t0).count();
+  rt_host_free(rgb); rt_host_free(ids);
   printf("Rendering seconds: %g\n", render_s);
   if (want_stats) {
-    rt_scene_info info;
-    printf("{\"rays\": %llu, \"shadow_rays\": %llu, \"kernel_ms\": %.3f, \"mrays_per_s\": %.2f, \"version\": \"%s\"}\n",
-           (unsigned long long)st.rays, (unsigned long long)st.shadow_rays, st.kernel_ms,
-           st.kernel_ms > 0 ? st.rays / (st.kernel_ms * 1e3) : 0.0, rt_version());
-    (void)info;
+    if (!rendered) { printf("{\"error\": \"render failed\", \"version\": \"%s\"}\n", rt_version()); return status ? status : 1; }
+    // algorithmic work of the minimal equivalent formulation per test (slab node test 24, Cramer triangle solve 61, sphere
+    // quadratic 20, shading 150 per ray), over the kernel time, against the 157.3 TFLOP/s FP32 vector peak of an MI355X
+    const double flop = 24.0 * counted.node_tests + 61.0 * counted.tri_tests + 20.0 * counted.sphere_tests + 150.0 * counted.rays;
+    const double tflops = st.kernel_ms > 0 ? flop / (st.kernel_ms * 1e-3) / 1e12 : 0.0;
+    printf("{\"rays\": %llu, \"shadow_rays\": %llu, \"gpus\": %d, \"parse_ms\": %.3f, \"octree_ms\": %.3f, \"upload_ms\": %.3f, "
+           "\"kernel_ms\": %.3f, \"copy_ms\": %.3f, \"png_ms\": %.3f, \"mrays_per_s\": %.2f, \"node_tests\": %llu, \"tri_tests\": %llu, "
+           "\"algorithmic_tflops\": %.2f, \"fp32_roofline_frac\": %.4f, \"version\": \"%s\"}\n",
+           (unsigned long long)st.rays, (unsigned long long)st.shadow_rays, n_dev, info.parse_seconds * 1e3, info.build_seconds * 1e3,
+           upload_s * 1e3, st.kernel_ms, st.copy_ms, png_s * 1e3, st.kernel_ms > 0 ? st.rays / (st.kernel_ms * 1e3) : 0.0,
+           (unsigned long long)counted.node_tests, (unsigned long long)counted.tri_tests, tflops, tflops / (157.3 * n_dev), rt_version());
   }
-  return 0;
+  return status;
 }

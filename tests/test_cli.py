@@ -34,3 +34,30 @@ def test_cli_renders_the_reference_image(tmp_path):
     assert "Using following defaults:" in out.stdout and "Oct taken seconds:" in out.stdout and "Rendering seconds:" in out.stdout
     ref = np.array(Image.open(os.path.join(rt.ROOT, "tests", "golden", "sphere_512_reference_image.png")).convert("RGB"))
     assert np.array_equal(np.array(Image.open(img).convert("RGB")), ref)
+
+
+@pytest.mark.gpu
+def test_cli_gpus_stats_and_dump_ids(tmp_path):
+    # --gpus 1 goes through the band partition, the RCCL gather and the unpack kernel; it must write the image the
+    # single-GPU path writes.  --stats is one JSON line with the time per phase; --dump-ids the primary-hit ids.
+    import json
+    a, b, ids = str(tmp_path / "a.png"), str(tmp_path / "b.png"), str(tmp_path / "ids.bin")
+    base = [RUN, "-s", "scenes/meshMedBunny.json", "-w", "200", "-h", "150"]
+    one = subprocess.run(base + ["-i", a, "--stats", "--dump-ids", ids], cwd=rt.ASSETS, stdout=subprocess.PIPE, text=True, timeout=120)
+    assert one.returncode == 0, one.stdout
+    many = subprocess.run(base + ["-i", b, "--gpus", "1", "--stats"], cwd=rt.ASSETS, stdout=subprocess.PIPE, text=True, timeout=120)
+    assert many.returncode == 0, many.stdout
+    assert np.array_equal(np.array(Image.open(a)), np.array(Image.open(b)))
+    s1, s2 = json.loads(one.stdout.strip().splitlines()[-1]), json.loads(many.stdout.strip().splitlines()[-1])
+    for key in ("parse_ms", "octree_ms", "upload_ms", "kernel_ms", "copy_ms", "png_ms", "mrays_per_s", "fp32_roofline_frac"):
+        assert key in s1 and key in s2
+    assert s1["rays"] == s2["rays"] > 200 * 150 and s1["kernel_ms"] > 0 and s2["gpus"] == 1
+    _, want_ids, _, _ = rt.DeviceScene(rt.Scene("scenes/meshMedBunny.json", 200, 150, 3)).render_host()
+    assert np.array_equal(np.fromfile(ids, np.int32).reshape(150, 200), want_ids)
+
+
+def test_cli_reports_an_unwritable_image(tmp_path):
+    # without a GPU the upload fails first (status 1, no CPU fallback); the status is never 0 when no image was written
+    out = subprocess.run([RUN, "-s", "scenes/sphere.json", "-i", str(tmp_path / "no_such_dir" / "x.png")], cwd=rt.ASSETS,
+                         stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=120)
+    assert out.returncode == 1

@@ -328,3 +328,83 @@ def test_synthetic_icosphere_scene(tmp_path, k, w, h):
     path, n = write_icosphere_scene(str(tmp_path), k)
     assert n == 20 * 4 ** k
     _check_scene(path, w, h, base_dir=str(tmp_path))
+
+
+def test_forked_contexts_share_one_upload_and_render_concurrently():
+    # rt_dscene_fork: a second render context (counters, queues) on the scene arrays already in HBM; frames in flight on
+    # two streams come out with the bytes of a frame rendered alone, and the arrays outlive the handle that uploaded them
+    import torch
+    w, h = 320, 208
+    for name in ("meshMedBunny", "meshTransparentBunny"):
+        first = rt.DeviceScene(rt.Scene("scenes/%s.json" % name, w, h, 3))
+        alone, _, _, st_alone = first.render_host(want_ids=False)
+        second = first.fork()
+        streams = [torch.cuda.Stream(device="cuda:0"), torch.cuda.Stream(device="cuda:0")]
+        bufs = [torch.zeros((h, w, 3), dtype=torch.uint8, device="cuda:0") for _ in range(4)]
+        torch.cuda.synchronize()
+        for k, buf in enumerate(bufs):
+            with torch.cuda.stream(streams[k % 2]):
+                (first, second)[k % 2].render_into(buf.data_ptr(), stream=streams[k % 2].cuda_stream)
+        torch.cuda.synchronize()
+        for buf in bufs:
+            assert np.array_equal(buf.cpu().numpy(), alone)
+        first.close()                       # the fork keeps the arrays alive
+        rgb, _, _, st = second.render_host(want_ids=False)
+        assert np.array_equal(rgb, alone) and st["rays"] == st_alone["rays"]
+
+
+def test_entry_points_leave_the_current_device_alone():
+    import torch
+    before = torch.cuda.current_device()
+    ds = rt.DeviceScene(rt.Scene("scenes/sphere.json", 64, 64, 3), device=0)
+    ds.render_host()
+    ds.close()
+    assert torch.cuda.current_device() == before
+
+
+@pytest.mark.parametrize("name,w,h", [("meshMedBunny", 200, 150), ("meshTransparentBunny", 160, 96), ("sphere", 5, 3)])
+def test_gathered_frame_on_the_visible_gpus(name, w, h):
+    # The multi-GPU product path (run --gpus N): bands on every visible device of this process, one RCCL gather, unpack on
+    # the first device.  On a one-GPU box N = 1 (the gather is rank 0 sending to itself); the frame must be rt_render_rows_host's.
+    import torch
+    n = torch.cuda.device_count()
+    scene = rt.Scene("scenes/%s.json" % name, w, h, 3)
+    dss = [rt.DeviceScene(scene, device=r) for r in range(n)]
+    comms = rt.Comm.init_all(list(range(n)))
+    want, _, _, st_want = dss[0].render_host(want_ids=False)
+    for _ in range(2):
+        rgb, st = rt.render_frame_gathered(dss, comms)
+        assert np.array_equal(rgb, want)
+        assert st["rays"] == st_want["rays"] and st["shadow_rays"] == st_want["shadow_rays"]
+    for c in comms:
+        c.close()
+
+
+def test_gather_and_unpack_entry_points_with_a_world_of_one():
+    # rt_comm_unique_id / rt_comm_init_rank / rt_gather_bands / rt_unpack_bands as one process per GPU would call them,
+    # here with one rank; the unpacking of 1, 2, 3 and 8 ranks' tiles is checked against the host-side assembly.
+    import torch
+    w, h = 200, 150
+    ds = rt.DeviceScene(rt.Scene("scenes/meshMedBunny.json", w, h, 3))
+    full, fids, _, _ = ds.render_host()
+    comm = rt.Comm.init_rank(rt.comm_unique_id(), 1, 0, 0)
+    for nranks in (1, 2, 3, 8):
+        nb_max = ds.band_count(16, 0, nranks)
+        tile_bytes = nb_max * 16 * w * 3
+        gathered = torch.zeros((nranks, nb_max * 16, w, 3), dtype=torch.uint8, device="cuda:0")
+        gids = torch.zeros((nranks, nb_max * 16, w), dtype=torch.int32, device="cuda:0")
+        for r in range(nranks):
+            local = torch.zeros((nb_max * 16, w, 3), dtype=torch.uint8, device="cuda:0")
+            ds.render_bands_into(local.data_ptr(), 16, r, nranks, ids_ptr=gids[r].data_ptr())
+            # a world of one: the "gather" moves the tile into rank r's slot of the gathered buffer
+            comm.gather_bands(local.data_ptr(), tile_bytes, gathered[r].data_ptr())
+            torch.cuda.synchronize()
+        image = torch.zeros((h, w, 3), dtype=torch.uint8, device="cuda:0")
+        rt.unpack_bands(gathered.data_ptr(), tile_bytes, nranks, 16, w, h, 3, image.data_ptr())
+        idimg = torch.zeros((h, w), dtype=torch.int32, device="cuda:0")
+        rt.unpack_bands(gids.data_ptr(), nb_max * 16 * w * 4, nranks, 16, w, h, 4, idimg.data_ptr())
+        torch.cuda.synchronize()
+        assert np.array_equal(image.cpu().numpy(), full)
+        assert np.array_equal(idimg.cpu().numpy(), fids)
+        assert np.array_equal(rt.assemble_bands([g.cpu().numpy() for g in gathered], h, 16), full)
+    comm.close()

@@ -57,7 +57,7 @@ def test_bounce_flag():
 
 def test_library_exports_every_declared_symbol():
     header = open(os.path.join(ROOT, "include", "rt_amd.h")).read()
-    declared = set(re.findall(r"^(?:int|void|const char\*)\s+(rt_[a-z_]+)\s*\(", header, re.M))
+    declared = set(re.findall(r"^(?:int|void\*?|const char\*)\s+(rt_[a-z_]+)\s*\(", header, re.M))
     assert declared == set(rt.ABI_SYMBOLS), declared ^ set(rt.ABI_SYMBOLS)
     L = C.CDLL(rt.LIB_PATH)
     for sym in declared:
