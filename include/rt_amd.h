@@ -132,6 +132,21 @@ int rt_dscene_fork(const rt_dscene* d, rt_dscene** out);
 int rt_render_rows(rt_dscene* d, int row_begin, int row_end, uint8_t* d_rgb, int32_t* d_ids, float* d_t,
                    void* stream, unsigned flags, rt_stats* stats);
 
+/* rt_render_rows for callers that cannot allocate device memory (code under HIP graph capture, tight serving loops,
+ * harnesses that forbid hipMalloc).  It has no counterpart in the reference.  Same arguments, same bytes, but every
+ * scratch buffer of the render (work counters; the queues, term lists and sort areas of scenes rendered from queues)
+ * lives in a 64 MiB array inside the library's code object instead of memory the rt_dscene allocates and grows: the
+ * call contains no hipMalloc / hipFree and nothing that allocates, and read-backs land in page-locked words set up
+ * by rt_scene_upload.  Limits: RT_RENDER_TIME is refused (RT_ERR_ARG; it creates events); a scene rendered from queues
+ * (glass meshes, or RT_RENDER_QUEUED) needs about 560 bytes of scratch per pixel of the call, so calls beyond about
+ * 119 000 pixels of such a scene are refused with RT_ERR_LIMIT - render fewer rows per call or pass RT_RENDER_STACKED,
+ * which needs the counters only; every other scene is accepted at any size.  Each GPU has ONE such array, shared by all
+ * rt_dscene handles of the process: calls that overlap on one GPU race on it (the counters and queue fills are cleared
+ * by each call that uses them, so calls in sequence are independent).  Without `stats`, and for scenes not rendered
+ * from queues, the call only enqueues kernels and memsets on `stream`. */
+int rt_render_rows_static(rt_dscene* d, int row_begin, int row_end, uint8_t* d_rgb, int32_t* d_ids, float* d_t,
+                          void* stream, unsigned flags, rt_stats* stats);
+
 /* Row-interleaved partition for rendering one image on several GPUs.  The image is cut into bands of
  * `band_rows` rows (a multiple of 16); rank r of nranks owns bands r, r+nranks, ...  rt_band_count
  * returns how many bands that is.  rt_render_bands renders them PACKED: band k of this rank starts at row

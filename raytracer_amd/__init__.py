@@ -29,7 +29,7 @@ RT_RENDER_STRIPS = 32
 # Every symbol include/rt_amd.h declares.
 ABI_SYMBOLS = (
     "rt_scene_load", "rt_scene_destroy", "rt_scene_get_info", "rt_scene_dump_tree", "rt_scene_dump_triangles",
-    "rt_scene_dump_camera", "rt_scene_upload", "rt_dscene_destroy", "rt_dscene_fork", "rt_render_rows", "rt_render_rows_host",
+    "rt_scene_dump_camera", "rt_scene_upload", "rt_dscene_destroy", "rt_dscene_fork", "rt_render_rows", "rt_render_rows_static", "rt_render_rows_host",
     "rt_host_alloc", "rt_host_free", "rt_band_count", "rt_render_bands", "rt_dscene_get_info",
     "rt_comm_unique_id", "rt_comm_init_rank", "rt_comm_init_all", "rt_comm_destroy", "rt_comm_group_begin", "rt_comm_group_end",
     "rt_gather_bands", "rt_unpack_bands", "rt_render_frame_gathered",
@@ -109,6 +109,7 @@ def lib():
         L.rt_host_free.restype = None
         L.rt_render_rows.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                      C.c_uint, C.POINTER(Stats)]
+        L.rt_render_rows_static.argtypes = L.rt_render_rows.argtypes
         L.rt_render_rows_host.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint,
                                           C.POINTER(Stats)]
         L.rt_band_count.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int]
@@ -239,6 +240,15 @@ class DeviceScene:
                                     C.byref(st) if want_stats else None))
         return st.as_dict() if want_stats else None
 
+
+    def render_static_into(self, rgb_ptr, row_begin=0, row_end=None, ids_ptr=None, t_ptr=None, stream=None, flags=0,
+                           want_stats=False):
+        """render_into through the entry point that allocates nothing (scratch in the library's static device array)."""
+        row_end = self.height if row_end is None else row_end
+        st = Stats() if want_stats else None
+        _check(lib().rt_render_rows_static(self.h, row_begin, row_end, rgb_ptr, ids_ptr, t_ptr, stream, flags,
+                                           C.byref(st) if want_stats else None))
+        return st.as_dict() if want_stats else None
 
     def band_count(self, band_rows, rank, nranks):
         n = lib().rt_band_count(self.h, band_rows, rank, nranks)

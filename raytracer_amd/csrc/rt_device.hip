@@ -121,6 +121,7 @@ struct RenderCtx {
   uint8_t* d_rgb = nullptr; int32_t* d_ids = nullptr; float* d_t = nullptr; size_t frame_px = 0;
   void* pinned = nullptr; size_t pinned_bytes = 0;
   hipStream_t host_stream = nullptr;
+  void* landing = nullptr;   // page-locked host words for read-backs (borrowed, never freed here); nullptr: pageable memory
   void release() {
     if (!arena.fixed) (void)hipFree(arena.base);
     arena = Arena();
@@ -142,6 +143,36 @@ int arena_reserve(Arena& a, size_t bytes, const char* what) {
   void* p = nullptr;
   HIP_TRY(hipMalloc(&p, bytes));
   a.base = (unsigned char*)p; a.bytes = bytes;
+  return RT_OK;
+}
+
+// ---- scratch of the entry point that allocates nothing (rt_render_rows_static) -------------------------------------
+// A fixed array in the code object: every GPU the library runs on holds its own copy, at its own address, until the
+// process ends.  Host code never uses the array's name as an address: the device address is asked for once per
+// device (static_scratch_setup, with that device current) and kept.
+#define RT_STATIC_SCRATCH_BYTES (64u << 20)
+#define RT_STATIC_MAX_DEVICES 64
+#define RT_STATIC_LANDING_BYTES (RT_COUNTER_BYTES + 256)
+static __device__ __align__(256) unsigned char scratch[RT_STATIC_SCRATCH_BYTES];
+
+struct StaticScratch {
+  unsigned char* ptr = nullptr;   // device address of `scratch` on this device
+  void* landing = nullptr;        // page-locked host words the counters and queue fills are copied into
+  bool ready = false;
+};
+StaticScratch g_static[RT_STATIC_MAX_DEVICES];
+std::mutex g_static_mutex;
+
+// Once per device, with that device current (called from rt_scene_upload, the library's per-device set-up).
+int static_scratch_setup(int device) {
+  if (device < 0 || device >= RT_STATIC_MAX_DEVICES) return RT_OK;   // such a device simply has no static entry point
+  std::lock_guard<std::mutex> lock(g_static_mutex);
+  StaticScratch& S = g_static[device];
+  if (S.ready) return RT_OK;
+  void* p = nullptr;
+  HIP_TRY(hipGetSymbolAddress(&p, HIP_SYMBOL(scratch)));
+  if (!S.landing) HIP_TRY(hipHostMalloc(&S.landing, RT_STATIC_LANDING_BYTES, hipHostMallocDefault));
+  S.ptr = (unsigned char*)p; S.ready = true;
   return RT_OK;
 }
 
@@ -186,6 +217,7 @@ extern "C" int rt_scene_upload(const rt_scene* s, int device, rt_dscene** out) {
 #undef UP
   V.n_spheres = (int32_t)s->spheres.size(); V.n_lights = (int32_t)s->lights.size(); V.has_oct = s->nodes.empty() ? 0 : 1; V.n_wnodes = (int32_t)s->nodes.size();
   if ((rc = arena_reserve(d->ctx.arena, RT_COUNTER_BYTES, "rt_scene_upload")) != RT_OK) { d->ctx.release(); return rc; }
+  if ((rc = static_scratch_setup(device)) != RT_OK) { d->ctx.release(); return rc; }
   *out = d.release();
   return RT_OK;
 }
@@ -234,7 +266,12 @@ int prepare_wavefront(const SceneArrays& S, RenderCtx& ctx, const RowMap& rows, 
     int rc = wavefront_layout((uint32_t)want_q, (uint32_t)want_t, stream, &L);
     if (rc != RT_OK) return rc;
     if (ctx.arena.bytes < L.total) {
-      if (!ctx.arena.fixed) HIP_TRY(hipStreamSynchronize(stream));   // nothing may still be using the arena that is about to be replaced
+      if (ctx.arena.fixed) {
+        rt_set_error("the bounce-ray queues of " + std::to_string(n_px) + " pixels need " + std::to_string(L.total) + " bytes of scratch and the static array holds " +
+                     std::to_string(ctx.arena.bytes) + ": render fewer rows per call, or pass RT_RENDER_STACKED (bounce rays on the lanes' stacks need none)");
+        return RT_ERR_LIMIT;
+      }
+      HIP_TRY(hipStreamSynchronize(stream));   // nothing may still be using the arena that is about to be replaced
       if ((rc = arena_reserve(ctx.arena, L.total, "bounce-ray queues")) != RT_OK) return rc;
     }
     ctx.wf_layout = L; ctx.wf_laid_out = true;
@@ -265,11 +302,13 @@ int render_wavefront(const SceneArrays& S, RenderCtx& ctx, const RowMap& rows, b
   q.term_keys = keys[0]; q.term_vals = vals[0]; q.term_count = counts + 2; q.term_cap = L.term_cap; q.enabled = 1; q.path_bits = path_bits; q.rays_per_wave = 64;
   rt_launch_wave_kernel(S.view, rows, true, count, d_rgb, d_ids, d_t, counters, tally, q, stream);
   HIP_TRY(hipGetLastError());
-  uint32_t h[4];
+  uint32_t h_pageable[4];
+  // (a context with page-locked landing words keeps the queue fills behind the counters' place there)
+  uint32_t* const h = ctx.landing ? (uint32_t*)((unsigned char*)ctx.landing + RT_COUNTER_BYTES) : h_pageable;
   int cur = 0;
   const float root_lo = -RT_INF / 4, root_side = RT_INF / 2;   // the octree's root cube (main.cu:25-31)
   for (int gen = 1; gen <= D + 1; gen++) {
-    HIP_TRY(hipMemcpyAsync(h, counts, sizeof h, hipMemcpyDeviceToHost, stream));
+    HIP_TRY(hipMemcpyAsync(h, counts, 4 * sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
     HIP_TRY(hipStreamSynchronize(stream));
     if (h[cur] > L.queue_cap || h[2] > L.term_cap) return RT_OK;   // would not fit: render the stacked way
     if (h[cur] == 0) break;
@@ -290,7 +329,7 @@ int render_wavefront(const SceneArrays& S, RenderCtx& ctx, const RowMap& rows, b
     HIP_TRY(hipGetLastError());
     cur ^= 1;
   }
-  HIP_TRY(hipMemcpyAsync(h, counts, sizeof h, hipMemcpyDeviceToHost, stream));
+  HIP_TRY(hipMemcpyAsync(h, counts, 4 * sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
   HIP_TRY(hipStreamSynchronize(stream));
   if (h[2] > L.term_cap || h[cur] != 0) return RT_OK;
   if (h[2] > 0) {
@@ -364,8 +403,9 @@ int launch_render(const SceneArrays& S, RenderCtx& ctx, RowMap rows, uint8_t* d_
     HIP_TRY(hipEventElapsedTime(&ms, ev.a, ev.b));
   }
   if (stats) {
-    static thread_local unsigned long long hc[RT_COUNTER_COPIES * RT_COUNTER_STRIDE];
-    HIP_TRY(hipMemcpyAsync(hc, ctx.arena.base, sizeof hc, hipMemcpyDeviceToHost, stream));
+    static thread_local unsigned long long hc_pageable[RT_COUNTER_COPIES * RT_COUNTER_STRIDE];
+    unsigned long long* const hc = ctx.landing ? (unsigned long long*)ctx.landing : hc_pageable;
+    HIP_TRY(hipMemcpyAsync(hc, ctx.arena.base, RT_COUNTER_BYTES, hipMemcpyDeviceToHost, stream));
     HIP_TRY(hipStreamSynchronize(stream));
     unsigned long long h[C_COUNT] = {0};
     for (int c = 0; c < RT_COUNTER_COPIES; c++) for (int k = 0; k < C_COUNT; k++) h[k] += hc[c * RT_COUNTER_STRIDE + k];
@@ -400,6 +440,25 @@ extern "C" int rt_render_rows(rt_dscene* d, int row_begin, int row_end, uint8_t*
   DeviceGuard g(d->scene->device);
   HIP_TRY(g.err);
   return launch_render(*d->scene, d->ctx, plain_rows(row_begin, row_end), d_rgb, d_ids, d_t, (hipStream_t)stream, flags, stats);
+}
+
+extern "C" int rt_render_rows_static(rt_dscene* d, int row_begin, int row_end, uint8_t* d_rgb, int32_t* d_ids, float* d_t,
+                                     void* stream, unsigned flags, rt_stats* stats) {
+  int rc = check_rows(d, d_rgb, row_begin, row_end, "rt_render_rows_static");
+  if (rc != RT_OK) return rc;
+  if (flags & RT_RENDER_TIME) { rt_set_error("rt_render_rows_static: RT_RENDER_TIME creates events; time the stream with events of your own"); return RT_ERR_ARG; }
+  const int device = d->scene->device;
+  if (device < 0 || device >= RT_STATIC_MAX_DEVICES || !g_static[device].ready) {   // (set up by rt_scene_upload on that device)
+    rt_set_error("rt_render_rows_static: no static scratch on this device");
+    return RT_ERR_DEVICE;
+  }
+  DeviceGuard g(device);
+  HIP_TRY(g.err);
+  // a context on the stack around this GPU's copy of the array: nothing in it is owned, nothing is freed
+  RenderCtx ctx;
+  ctx.arena.base = g_static[device].ptr; ctx.arena.bytes = RT_STATIC_SCRATCH_BYTES; ctx.arena.fixed = true;
+  ctx.landing = g_static[device].landing;
+  return launch_render(*d->scene, ctx, plain_rows(row_begin, row_end), d_rgb, d_ids, d_t, (hipStream_t)stream, flags, stats);
 }
 
 extern "C" int rt_band_count(const rt_dscene* d, int band_rows, int rank, int nranks) {

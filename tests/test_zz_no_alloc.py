@@ -1,0 +1,87 @@
+"""rt_render_rows_static, the entry point that allocates nothing: its scratch (work counters, and for scenes rendered
+from queues the ray queues, term lists and sort areas) is a fixed array inside the library's code object.  Through the C
+ABI it must give the bytes, ids, distances and counters of rt_render_rows, call after call, the later call on a smaller
+input (what the earlier one left in the array must not leak into it), without the device's free memory moving."""
+import numpy as np
+import pytest
+
+import raytracer_amd as rt
+
+pytestmark = pytest.mark.gpu
+
+COUNTERS = ("rays", "shadow_rays", "rays_traced", "ub_leave_level0", "ub_level_overflow", "ub_stack_overflow")
+
+
+def _both(ds, torch, w, h, r0, r1, flags=0):
+    out = []
+    for static in (False, True):
+        rgb = torch.zeros((h, w, 3), dtype=torch.uint8, device="cuda:0")
+        ids = torch.full((h, w), -9, dtype=torch.int32, device="cuda:0")
+        ts = torch.full((h, w), -1.0, dtype=torch.float32, device="cuda:0")
+        torch.cuda.synchronize()
+        free0 = torch.cuda.mem_get_info()[0]
+        f = ds.render_static_into if static else ds.render_into
+        st = f(rgb.data_ptr(), r0, r1, ids_ptr=ids.data_ptr(), t_ptr=ts.data_ptr(), flags=flags, want_stats=True)
+        torch.cuda.synchronize()
+        if static:
+            assert torch.cuda.mem_get_info()[0] == free0, "device memory was allocated or freed inside the call"
+        out.append((rgb.cpu().numpy(), ids.cpu().numpy(), ts.cpu().numpy(), st))
+    (rgb_a, ids_a, ts_a, st_a), (rgb_b, ids_b, ts_b, st_b) = out
+    assert np.array_equal(rgb_a, rgb_b) and np.array_equal(ids_a, ids_b) and np.array_equal(ts_a.view(np.uint32), ts_b.view(np.uint32))
+    for k in COUNTERS:
+        assert st_a[k] == st_b[k], (k, st_a[k], st_b[k])
+    assert st_b["rays"] >= (r1 - r0) * w
+    return st_b
+
+
+@pytest.mark.parametrize("name,flags", [("meshTransparentBunny", 0), ("meshMedBunny", 0), ("heliumAttenuatedSphere", rt.RT_RENDER_QUEUED),
+                                        ("meshTransparentBunny", rt.RT_RENDER_COUNT_TESTS)])
+def test_static_entry_point_matches_render_rows_on_two_calls_in_a_row(name, flags):
+    import torch
+    w, h = 256, 192
+    ds = rt.DeviceScene(rt.Scene("scenes/%s.json" % name, w, h, 3))
+    big = _both(ds, torch, w, h, 0, h, flags)             # the whole frame: 49 152 pixels, queues and term lists filled
+    small = _both(ds, torch, w, h, 70, 110, flags)        # then 40 rows of it: a smaller input right behind
+    assert small["rays"] < big["rays"]
+    # a smaller scene on another handle shares the same array
+    ds2 = rt.DeviceScene(rt.Scene("scenes/%s.json" % name, 96, 64, 3))
+    _both(ds2, torch, 96, 64, 0, 64, flags)
+    _both(ds, torch, w, h, 0, 9, flags)
+
+
+def test_static_entry_point_without_stats_is_asynchronous_and_equal():
+    import torch
+    w, h = 320, 200
+    ds = rt.DeviceScene(rt.Scene("scenes/lambertBPHSpheres.json", w, h, 3))
+    want, wids, _, _ = ds.render_host()
+    stream = torch.cuda.Stream()
+    rgb = torch.zeros((h, w, 3), dtype=torch.uint8, device="cuda:0")
+    ids = torch.zeros((h, w), dtype=torch.int32, device="cuda:0")
+    with torch.cuda.stream(stream):
+        ds.render_static_into(rgb.data_ptr(), ids_ptr=ids.data_ptr(), stream=stream.cuda_stream)
+        ds.render_static_into(rgb.data_ptr(), 50, 60, ids_ptr=ids.data_ptr(), stream=stream.cuda_stream)
+    stream.synchronize()
+    assert np.array_equal(rgb.cpu().numpy(), want) and np.array_equal(ids.cpu().numpy(), wids)
+
+
+def test_static_entry_point_limits():
+    import torch
+    w, h = 640, 480                                         # 307 200 pixels of a scene rendered from queues: beyond the array
+    ds = rt.DeviceScene(rt.Scene("scenes/meshTransparentBunny.json", w, h, 3))
+    rgb = torch.zeros((h, w, 3), dtype=torch.uint8, device="cuda:0")
+    with pytest.raises(rt.RtError) as e:
+        ds.render_static_into(rgb.data_ptr())
+    assert e.value.status == -4 and "RT_RENDER_STACKED" in str(e.value)
+    with pytest.raises(rt.RtError) as e:
+        ds.render_static_into(rgb.data_ptr(), flags=rt.RT_RENDER_TIME)
+    assert e.value.status == -1
+    # in slices that fit, and on the lanes' stacks in one piece: the frame of rt_render_rows either way
+    want, _, _, _ = ds.render_host(want_ids=False)
+    for r0 in range(0, h, 160):
+        ds.render_static_into(rgb.data_ptr(), r0, min(h, r0 + 160))
+    torch.cuda.synchronize()
+    assert np.array_equal(rgb.cpu().numpy(), want)
+    rgb.zero_()
+    ds.render_static_into(rgb.data_ptr(), flags=rt.RT_RENDER_STACKED)
+    torch.cuda.synchronize()
+    assert np.array_equal(rgb.cpu().numpy(), want)
