@@ -19,7 +19,7 @@ $(CSRC)/rt_host.o: $(CSRC)/rt_host.cpp $(CSRC)/rt_internal.h include/rt_amd.h
 
 HIPOBJS := $(CSRC)/rt_device.o $(CSRC)/rt_kernel_lane.o $(CSRC)/rt_kernel_wave.o $(CSRC)/rt_sort.o $(CSRC)/rt_gather.o
 
-$(CSRC)/%.o: $(CSRC)/%.hip $(CSRC)/rt_kernels.h $(CSRC)/rt_internal.h $(CSRC)/rt_math.h include/rt_amd.h
+$(CSRC)/%.o: $(CSRC)/%.hip $(CSRC)/rt_kernels.h $(CSRC)/rt_internal.h $(CSRC)/rt_math.h $(CSRC)/rt_trace_asm.inc include/rt_amd.h
 	$(HIPCC) $(HIPFLAGS) -c $< -o $@
 
 $(LIB): $(CSRC)/rt_host.o $(HIPOBJS)

@@ -723,9 +723,19 @@ void load_scene_into(rt_scene& sc, const std::string& scene_path, const std::str
       for (int k = 0; k < 3; k++) { t.v0[k] = g.v0[k]; t.e1[k] = g.e1[k]; }
       t.e2xy[0] = g.e2[0]; t.e2xy[1] = g.e2[1]; t.e2yz[0] = g.e2[1]; t.e2yz[1] = g.e2[2]; t.e2zx[0] = g.e2[2]; t.e2zx[1] = g.e2[0];
       t.id = sc.leaf_refs[r];
+      // third column of cofactors (rt_cofactor_solve: m02, m12, m22), operation for operation
+      t.nx = g.e1[1] * g.e2[2] - g.e1[2] * g.e2[1];
+      t.ny = -g.e1[0] * g.e2[2] + g.e1[2] * g.e2[0];
+      t.nz = g.e1[0] * g.e2[1] - g.e1[1] * g.e2[0];
     }
     sc.nodes.push_back(RtNode{});   // pad; not counted in info.n_nodes
     sc.wnodes.assign(sc.nodes.size() * RT_NODE_VARIANTS, RtWaveNode{});
+    std::vector<uint8_t> sibling(sc.nodes.size(), 0);   // position of a record among the eight children of its parent
+    for (size_t i = 0; i + 1 < sc.nodes.size(); i++) {
+      int32_t first, count;
+      memcpy(&first, &sc.nodes[i].a[3], 4); memcpy(&count, &sc.nodes[i].b[3], 4);
+      if (count < 0) for (int c = 0; c < 8; c++) sibling[first + c] = (uint8_t)c;
+    }
     for (size_t i = 0; i + 1 < sc.nodes.size(); i++) {
       const RtNode& n = sc.nodes[i];
       const float lo[3] = {n.a[0], n.a[1], n.b[2]}, hi[3] = {n.b[0], n.b[1], n.a[2]};
@@ -740,6 +750,7 @@ void load_scene_into(rt_scene& sc, const std::string& scene_path, const std::str
         }
         meta = 0x80000000u | occupied;
       }
+      meta |= (uint32_t)sibling[i] << 24;
       for (int v = 0; v < RT_NODE_VARIANTS; v++) {
         RtWaveNode& w = sc.wnodes[(size_t)v * sc.nodes.size() + i];
         for (int k = 0; k < 3; k++) { const bool sw = (v >> k) & 1; w.lohi[2 * k] = sw ? hi[k] : lo[k]; w.lohi[2 * k + 1] = sw ? lo[k] : hi[k]; }

@@ -54,7 +54,8 @@ struct RtNode { float a[4]; float b[4]; };
 // The same node as the wave-synchronous kernel reads it, 32 B = one 8-dword scalar load.  The two planes of an
 // axis sit in adjacent dwords so that a packed-fp32 instruction can take them straight from an SGPR pair.
 //   p.x q.x p.y q.y | p.z q.z first meta
-//   meta: leaf -> number of triangles (0..50); branch -> 0x80000000 | bit c set when child c is not an empty leaf
+//   meta: leaf -> number of triangles (0..50); branch -> 0x80000000 | bit c set when child c is not an empty leaf;
+//         either way bits 24..26 hold the record's own position among its eight siblings (0 for the root)
 // The array is stored RT_NODE_VARIANTS = 8 times over (variant v of node i is record v * n + i, n counting the pad
 // record, so that a walk stays inside one dense copy):  in variant v the pair of axis k is
 // (lo, hi) when bit k of v is clear and (hi, lo) when it is set, lo / hi being the min / max corner
@@ -72,8 +73,11 @@ struct RtTriGeom { float v0[3]; float e1[3]; float e2[3]; int32_t mesh; int32_t 
 // Leaf-ordered copy of the intersection record, 64 B, read with wave-uniform addresses into SGPRs.  The pairs that
 // the first stage of the triangle test multiplies with packed-fp32 instructions sit in even-aligned adjacent dwords, so
 // they are used straight from SGPR pairs (e2 is stored as its three cyclic pairs):
-//   v0.x v0.y v0.z id | e1.x e1.y e1.z - | e2.x e2.y e2.y e2.z | e2.z e2.x - -
-struct alignas(64) RtTriLeaf { float v0[3]; int32_t id; float e1[3]; int32_t pad0; float e2xy[2]; float e2yz[2]; float e2zx[2]; int32_t pad1[2]; };
+//   v0.x v0.y v0.z id | e1.x e1.y e1.z n.x | e2.x e2.y e2.y e2.z | e2.z e2.x n.y n.z
+// n = e1 x e2 with the rounding of the third cofactor column of triangle.cu:121-133 (m02, m12, m22): it depends on the
+// triangle alone, so the host forms it once (same float operations, no contraction) instead of every ray that gets
+// as far as the t numerator.
+struct alignas(64) RtTriLeaf { float v0[3]; int32_t id; float e1[3]; float nx; float e2xy[2]; float e2yz[2]; float e2zx[2]; float ny, nz; };
 
 // Triangle shading record, 64 B, read once per closest hit: v1, v2 and the three vertex normals.
 struct RtTriShade { float v1[3]; float v2[3]; float n0[3]; float n1[3]; float n2[3]; float pad; };

@@ -104,7 +104,11 @@ __device__ __forceinline__ void trace_wave(const float4* __restrict__ nodes, int
   // variant whose plane pairs are already in (near, far) order for those signs.  Otherwise variant 0 = (lo, hi).
   const uint64_t sx = __builtin_amdgcn_ballot_w64(d.x < 0.f) & live, sy = __builtin_amdgcn_ballot_w64(d.y < 0.f) & live,
                  sz = __builtin_amdgcn_ballot_w64(d.z < 0.f) & live;
-  const bool presorted = !any_zero && (sx == 0ull || sx == live) && (sy == 0ull || sy == live) && (sz == 0ull || sz == live);
+  // (a component so small that its inverse overflows takes the general path: the scan loop's fused plane distances
+  //  need finite c = e * inv)
+  const float INF = __builtin_inff();
+  const bool inv_finite = (__builtin_amdgcn_ballot_w64(!(fabsf(inv.x) < INF && fabsf(inv.y) < INF && fabsf(inv.z) < INF)) & live) == 0ull;
+  const bool presorted = !any_zero && inv_finite && (sx == 0ull || sx == live) && (sy == 0ull || sy == live) && (sz == 0ull || sz == live);
   const uint32_t variant = uni(presorted ? ((sx ? 1u : 0u) | (sy ? 2u : 0u) | (sz ? 4u : 0u)) : 0u);   // uni(): keeps the node addresses scalar
   nodes += 2 * (size_t)variant * (size_t)n_wnodes;   // each variant is a dense copy of the whole array
 
@@ -133,8 +137,20 @@ __device__ __forceinline__ void trace_wave(const float4* __restrict__ nodes, int
     auto rec8 = [](cnode_ptr p) { return *(cnode8_ptr)p; };
     f8 nx = {0, 0, 0, 0, 0, 0, 0, 0};
     // margin that no node of this tree exceeds for this ray (the root's planes bound every node's)
+    // The assembly scan loop forms a plane distance by one fused multiply-add, p * inv - c with c = e * inv (rt_math.h,
+    // rt_slab_fused); the compiled loops of the instrumented variants keep the two-step form (same decisions either way:
+    // both classifications only ever abstain).
     float neg_eb = 0.f;
-    if (presorted) { const float4 ra = rec(cnodes), rb = rec(cnodes + 1); neg_eb = -rt_slab_margin_bound(ra.x, ra.y, ra.z, ra.w, rb.x, rb.y, e, inv, hit.t); }
+    RtVec3 fc = {0.f, 0.f, 0.f};
+    constexpr bool FUSED = !COUNT && !PATHS;
+    if (presorted) {
+      const float4 ra = rec(cnodes), rb = rec(cnodes + 1);
+      if (FUSED) {
+        const RtSlabFused fu = rt_slab_fused(e, inv);
+        fc = fu.c;
+        neg_eb = -rt_slab_margin_bound_fused(ra.x, ra.y, ra.z, ra.w, rb.x, rb.y, e, inv, fu, hit.t);
+      } else neg_eb = -rt_slab_margin_bound(ra.x, ra.y, ra.z, ra.w, rb.x, rb.y, e, inv, hit.t);
+    }
 #ifdef RT_WAVE_CULL
     // Measurement build (off in the product; tools/build_variant.sh cull -DRT_WAVE_CULL): the children of a branch are
     // put in front of the wave's rays as a whole before they are scanned.  On the 4K dragon frame it takes 54 % of the
@@ -162,6 +178,79 @@ __device__ __forceinline__ void trace_wave(const float4* __restrict__ nodes, int
       for (int k = 0; k < 3; k++) { cull_lds[k] = cu_eA[k]; cull_lds[4 + k] = cu_eB[k]; cull_lds[8 + k] = cu_iS[k]; cull_lds[12 + k] = cu_iL[k]; }
       cull_lds[3] = cu_neb;
     }
+#endif
+#ifndef RT_NO_ASM_WALK
+    // ---- The walk of a wave whose rays agree on their direction signs (nearly all primary and point-light shadow waves),
+    // as one block of assembly (rt_trace_asm.inc, written by tools/gen_trace_asm.py): scan of a branch's children with
+    // fused plane distances, margin and acceptance, descent (the stack entry is one v_writelane per word, the stack
+    // pointer lives in M0), ascent, and the leaf loop with the three numerator stages of the triangle test on two sets
+    // of record registers filled in turn.  What the compiler makes of the same walk spends most of its scalar
+    // instructions moving records and lane masks between register sets; the scalar unit, which a compute unit's four
+    // SIMDs share, is what this kernel keeps busiest.  The block leaves for two things only and is entered again
+    // afterwards: the exact node test of lanes the classification could not decide (reason 1: about 1 % of the node
+    // tests) and the quotients of triangle candidates (reason 2: 2.5 % of the triangle tests).  Reason 0: the walk is over.
+    // Registers (fixed, named in the generator): s[36:67] two triangle records, s[68:69] address of the current
+    // branch's children, s70 children left (bit 8 always set: "child 8" is the record behind the block, requested but
+    // never tested), s71 index of child 0, s[72:73] lanes that entered the branch, s[74:75] those of them still
+    // undecided, s[76:77] undecided lanes of the wave, s78 child whose record is in s[84:91], s79/s80 links of the child
+    // just tested, s81 byte offset, s[82:83] node array, s[92:93] triangle array, s[94:95] accepted lanes, s[96:97] undecided lanes,
+    // s[28:29] triangle candidates, s[20:21] next triangle record, s22 triangles left in the leaf, s[24:25] lanes
+    // whose hit changed in the leaf, s30 reason / re-entry, s31 id of the candidate triangle; v[40:59] the ray
+    // (origin, negated direction in the pairs the first stage multiplies, inverse direction, e * inv, margin terms,
+    // closest hit so far, shadow-ray length), v[60:63] the wave's stack, v32 v33 v35 v36 determinant and numerators
+    // of a candidate, v34 v37:v39 v64:v79 scratch.
+    if (presorted && FUSED && (rem & 0xffu) != 0u) {
+      uint64_t a_blk = (uint64_t)(uintptr_t)(nodes + NS * (size_t)top_first);
+      uint32_t a_rem = rem | 0x100u, a_first = top_first, a_idx = 0u, a_rfirst = 0u, a_rmeta = 0u, a_k = 0u, a_res = 0u, a_prim = 0u, a_sp = 0u;
+      uint64_t a_tmask = live, a_mine = live, a_live = live, a_acc = 0ull, a_und = 0ull, a_pass = 0ull, a_tp = 0ull, a_chg = 0ull;
+      const uint64_t a_nodes = (uint64_t)(uintptr_t)nodes, a_tri = (uint64_t)(uintptr_t)tri_leaf;
+      const uint32_t a_sign = 0x80000000u;
+      const float cmax = rt_max3(fabsf(fc.x), fabsf(fc.y), fabsf(fc.z));
+      float a_det = 0.f, a_nb = 0.f, a_ng = 0.f, a_nt = 0.f;
+      for (;;) {
+        asm volatile(
+#include "rt_trace_asm.inc"
+            : "+{s[68:69]}"(a_blk), "+{s70}"(a_rem), "+{s71}"(a_first), "+{s[72:73]}"(a_tmask), "+{s[74:75]}"(a_mine), "+{s[76:77]}"(a_live),
+              "+{s78}"(a_idx), "+{s79}"(a_rfirst), "+{s80}"(a_rmeta), "+{s[94:95]}"(a_acc), "+{s[96:97]}"(a_und), "+{s[28:29]}"(a_pass),
+              "+{s[20:21]}"(a_tp), "+{s22}"(a_k), "+{s[24:25]}"(a_chg), "+{s30}"(a_res), "+{s31}"(a_prim), "+{m0}"(a_sp),
+              "+{v60}"(st.first), "+{v61}"(st.cur), "+{v62}"(st.mask_lo), "+{v63}"(st.mask_hi),
+              "={v32}"(a_det), "={v33}"(a_nb), "={v35}"(a_ng), "={v36}"(a_nt)
+            : "{s[82:83]}"(a_nodes), "{s[92:93]}"(a_tri), "{s23}"(a_sign), "{v[40:41]}"(e_xy), "{v42}"(e.z), "{v[44:45]}"(c_zx), "{v[46:47]}"(c_yz),
+              "{v[48:49]}"(c_yx), "{v50}"(inv.x), "{v51}"(inv.y), "{v52}"(inv.z), "{v53}"(fc.x), "{v54}"(fc.y), "{v55}"(fc.z), "{v56}"(cmax),
+              "{v57}"(neg_eb), "{v58}"(hit.t), "{v59}"(stop_t)
+            : "s36", "s37", "s38", "s39", "s40", "s41", "s42", "s43", "s44", "s45", "s46", "s47", "s48", "s49", "s50", "s51", "s52", "s53", "s54", "s55",
+              "s56", "s57", "s58", "s59", "s60", "s61", "s62", "s63", "s64", "s65", "s66", "s67", "s81", "s84", "s85", "s86", "s87", "s88", "s89", "s90",
+              "s91", "s98", "s99", "s26", "s27", "v34", "v37", "v38", "v39", "v64", "v65", "v66", "v67", "v68", "v69", "v70", "v71", "v72", "v73", "v74",
+              "v75", "v76", "v77", "v78", "v79", "vcc", "scc");
+        if (a_res == 0u) break;
+        if (a_res == 1u) {
+          // the exact test for the lanes in a_und: the planes of the child just tested are read again
+          const uint32_t c_cur = (a_rmeta >> 24) & 7u;
+          const cnode_ptr cb = (cnode_ptr)a_blk;
+          const float4 na = rec(cb + NS * c_cur), nb = rec(cb + NS * c_cur + 1);
+          RtVec3 dd = d, ee = e; float T = hit.t;
+          asm volatile("" : "+v"(dd.x), "+v"(dd.y), "+v"(dd.z), "+v"(ee.x), "+v"(ee.y), "+v"(ee.z), "+v"(T));
+          const RtRayConst rc = rt_ray_const(dd);
+          const bool wx = (variant & 1u) != 0u, wy = (variant & 2u) != 0u, wz = (variant & 4u) != 0u;
+          const RtVec3 ini = {wx ? na.y : na.x, wy ? na.w : na.z, wz ? nb.x : nb.y}, end = {wx ? na.x : na.y, wy ? na.z : na.w, wz ? nb.y : nb.x};
+          const float S = rt_node_score(ini, end, ee, dd, rc, rt_t_float(rc, T));
+          uint64_t pos_m = __builtin_amdgcn_ballot_w64(S > 0.f);
+          const uint64_t tie_m = __builtin_amdgcn_ballot_w64(S == 0.f) & a_und;
+          if (tie_m) {   // a boundary case: settle it with the compare form
+            const bool ex = rt_node_accept_exact(ini, end, ee, dd, rc, rt_t_const(rc, T));
+            pos_m = (pos_m & ~tie_m) | (__builtin_amdgcn_ballot_w64(ex) & tie_m);
+          }
+          a_acc |= pos_m & a_und;
+        } else if ((a_pass >> lane) & 1ull) {   // the reference's quotients decide (triangle.cu:131-137)
+          RtTriNum n;
+          n.det = a_det; n.nb = a_nb; n.ng = a_ng; n.nt = a_nt;
+          float t, bet, gam;
+          if (rt_triangle_finish(n, hit.t, t, bet, gam)) { hit.t = t; hit.prim = (int32_t)a_prim; hit.bet = bet; hit.gam = gam; }
+        }
+      }
+      live = a_live;
+      if (!live) return;
+    } else {
 #endif
     cnode_ptr blk = cnodes + NS * top_first;   // records of the current branch's children
     { const uint32_t c = (uint32_t)__builtin_ctz(rem | 0x100u); nx = rec8(blk + NS * c); }
@@ -208,7 +297,7 @@ __device__ __forceinline__ void trace_wave(const float4* __restrict__ nodes, int
             const cnode_ptr rp = (cnode_ptr)((const __attribute__((address_space(4))) char*)blk + off);                                 \
             nx = rec8(rp);                                                                                         \
           }                                                                                                                             \
-          if (PATHS && r_meta != 0u) tl.w[1]++;                                                                                         \
+          if (PATHS && (r_meta & 0x800000ffu) != 0u) tl.w[1]++;                                                                                       \
           if (COUNT && ((mine_m >> lane) & 1ull)) tl.node++;   /* w[1]: iterations the plain variant also makes */                      \
           acc_m = 0ull; und_m = 0ull;                                                                                                   \
           __VA_ARGS__                                                                                                                   \
@@ -228,6 +317,14 @@ __device__ __forceinline__ void trace_wave(const float4* __restrict__ nodes, int
             }                                                                                                                           \
           }
 #ifndef RT_NO_ASM_SCAN
+        // (measurement builds: instructions without effect in the scan loop, to see what the loop's time follows)
+#if defined(RT_JUNK_VALU)
+#define RT_JUNK_ASM "v_mul_f32 %[x], %[ix], %[iy]\n v_mul_f32 %[r], %[ix], %[iy]\n v_mul_f32 %[tc], %[ix], %[iy]\n v_mul_f32 %[x], %[iz], %[iy]\n v_mul_f32 %[r], %[iz], %[iy]\n v_mul_f32 %[tc], %[ix], %[iz]\n"
+#elif defined(RT_JUNK_SALU)
+#define RT_JUNK_ASM "s_mov_b32 %[tmp], %[rem]\n s_mov_b32 %[tmp], %[prev]\n s_mov_b32 %[tmp], %[rem]\n s_mov_b32 %[tmp], %[prev]\n s_mov_b32 %[tmp], %[rem]\n s_mov_b32 %[tmp], %[prev]\n"
+#else
+#define RT_JUNK_ASM
+#endif
         if (presorted && !COUNT && !PATHS) {
           // The same loop, its common part written out: children that every ray of the wave misses by more than the ray's
           // largest margin never leave the assembly (consume the record, request the next sibling into the same eight
@@ -241,12 +338,12 @@ __device__ __forceinline__ void trace_wave(const float4* __restrict__ nodes, int
             asm volatile(
                 "L_scan_%=:\n"
                 "s_waitcnt lgkmcnt(0)\n"
-                "v_sub_f32 %[t0], s84, %[ex]\n"
-                "v_sub_f32 %[t1], s85, %[ex]\n"
-                "v_sub_f32 %[t2], s86, %[ey]\n"
-                "v_sub_f32 %[t3], s87, %[ey]\n"
-                "v_sub_f32 %[t4], s88, %[ez]\n"
-                "v_sub_f32 %[t5], s89, %[ez]\n"
+                "v_fma_f32 %[t0], s84, %[ix], -%[cx]\n"
+                "v_fma_f32 %[t1], s85, %[ix], -%[cx]\n"
+                "v_fma_f32 %[t2], s86, %[iy], -%[cy]\n"
+                "v_fma_f32 %[t3], s87, %[iy], -%[cy]\n"
+                "v_fma_f32 %[t4], s88, %[iz], -%[cz]\n"
+                "v_fma_f32 %[t5], s89, %[iz], -%[cz]\n"
                 "s_mov_b32 %[first], s90\n"
                 "s_mov_b32 %[meta], s91\n"
                 "s_mov_b32 %[prev], %[rem]\n"
@@ -256,12 +353,7 @@ __device__ __forceinline__ void trace_wave(const float4* __restrict__ nodes, int
                 "s_ff1_i32_b32 %[tmp], %[tmp]\n"
                 "s_lshl_b32 %[tmp], %[tmp], 5\n"
                 "s_load_dwordx8 s[84:91], %[blk], %[tmp] offset:0x0\n"
-                "v_mul_f32 %[t0], %[t0], %[ix]\n"
-                "v_mul_f32 %[t1], %[t1], %[ix]\n"
-                "v_mul_f32 %[t2], %[t2], %[iy]\n"
-                "v_mul_f32 %[t3], %[t3], %[iy]\n"
-                "v_mul_f32 %[t4], %[t4], %[iz]\n"
-                "v_mul_f32 %[t5], %[t5], %[iz]\n"
+                RT_JUNK_ASM
                 "v_max3_f32 %[tn], %[t0], %[t2], %[t4]\n"
                 "v_min3_f32 %[tf], %[t1], %[t3], %[t5]\n"
                 "v_cmp_lt_f32 vcc, 0, %[tn]\n"
@@ -279,7 +371,7 @@ __device__ __forceinline__ void trace_wave(const float4* __restrict__ nodes, int
                 : [nx] "+{s[84:91]}"(nx), [rem] "+s"(rem), [first] "=&s"(r_first), [meta] "=&s"(r_meta), [prev] "=&s"(prev), [tmp] "=&s"(tmp),
                   [nr] "=&s"(notrej), [t0] "=&v"(t0), [t1] "=&v"(t1), [t2] "=&v"(t2), [t3] "=&v"(t3), [t4] "=&v"(t4), [t5] "=&v"(t5),
                   [tn] "=&v"(tn), [tf] "=&v"(tf), [span] "=&v"(span), [tc] "=&v"(tc), [x] "=&v"(x), [r] "=&v"(r)
-                : [blk] "s"(blk_bits), [mine] "s"(mine_m), [ex] "v"(e.x), [ey] "v"(e.y), [ez] "v"(e.z), [ix] "v"(inv.x), [iy] "v"(inv.y),
+                : [blk] "s"(blk_bits), [mine] "s"(mine_m), [cx] "v"(fc.x), [cy] "v"(fc.y), [cz] "v"(fc.z), [ix] "v"(inv.x), [iy] "v"(inv.y),
                   [iz] "v"(inv.z), [T] "v"(hit.t), [neb] "v"(neg_eb)
                 : "vcc", "scc");
             rem_cur = uni(prev);
@@ -288,7 +380,7 @@ __device__ __forceinline__ void trace_wave(const float4* __restrict__ nodes, int
             RtSlabHead hd;
             hd.tN = tn; hd.tF = tf; hd.span = span; hd.front = tn > 0.f; hd.tc = tc; hd.x = x; hd.r = r;
             bool c_acc, c_rej;
-            rt_node_slab_tail(hd, t0, t1, t2, t3, t4, t5, hit.t, c_acc, c_rej);
+            rt_node_slab_tail_fused(hd, t0, t1, t2, t3, t4, t5, hit.t, rt_max3(fabsf(fc.x), fabsf(fc.y), fabsf(fc.z)), c_acc, c_rej);
             acc_m = __builtin_amdgcn_ballot_w64(c_acc) & mine_m;
             und_m = mine_m & ~(acc_m | __builtin_amdgcn_ballot_w64(c_rej));
             if ((acc_m | und_m) != 0ull || rem == 0u) break;
@@ -410,7 +502,7 @@ __device__ __forceinline__ void trace_wave(const float4* __restrict__ nodes, int
 #endif
         na = float4{nx[0], nx[1], nx[2], nx[3]}; nb = float4{nx[4], nx[5], nx[6], nx[7]};
         { const uint32_t c = (uint32_t)__builtin_ctz(rem | 0x100u); nx = rec8(blk + NS * c); }
-        if (PATHS && uni(__float_as_uint(nb.w)) != 0u) tl.w[1]++;
+        if (PATHS && (uni(__float_as_uint(nb.w)) & 0x800000ffu) != 0u) tl.w[1]++;
         if (COUNT && ((mine_m >> lane) & 1ull)) tl.node++;
         if (!any_zero) {
           bool c_acc, c_rej;
@@ -492,7 +584,7 @@ __device__ __forceinline__ void trace_wave(const float4* __restrict__ nodes, int
         nx = rec8(blk + NS * c);
         continue;
       }
-      const int32_t count = (int32_t)meta;
+      const int32_t count = (int32_t)(meta & 0xffu);   // (bits 24..26: the record's position among its siblings)
       // leaf: every triangle in insertion order (octtree.cu:264-274); all lanes in acc_m test the same triangle
       if (COUNT && ((acc_m >> lane) & 1ull)) { tl.leaf++; tl.tri += (uint32_t)count; }
       if (count == 0) continue;
@@ -576,6 +668,9 @@ __device__ __forceinline__ void trace_wave(const float4* __restrict__ nodes, int
         if (mine_m == 0ull) rem = 0u;   // nobody left in this branch
       }
     }
+#ifndef RT_NO_ASM_WALK
+    }
+#endif
   }
   if (n_spheres > 0) {
     bool mine_live = ((live >> lane) & 1ull) != 0ull;

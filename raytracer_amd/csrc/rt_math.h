@@ -405,6 +405,50 @@ RT_HD void rt_node_slab_fast(float lox, float hix, float loy, float hiy, float l
   const float z0 = (loz - e.z) * inv.z, z1 = (hiz - e.z) * inv.z;
   rt_node_slab_sorted(fminf(x0, x1), fmaxf(x0, x1), fminf(y0, y1), fmaxf(y0, y1), fminf(z0, z1), fmaxf(z0, z1), T, acc, rej);
 }
+// The classification on plane distances formed by ONE fused operation each, t' = fl(p * inv - c) with c = fl(e * inv) held
+// per ray, instead of fl(fl(p - e) * inv): half the instructions per node in the wave kernel's scan loop.  Both forms
+// approximate tau = (p - e) * inv: |t - tau| <= 2^-23 |tau| for the two-step form, |t' - tau| <= 2^-24 (|c| + |t'|) for
+// the fused one, so |t' - t| <= 2^-22 max(|t|, |c|).  The classification stays conservative when its margin also
+// scales with C = max |c_k|: M becomes max(M, C), E = 2^-17 (max(M, C) + T), which leaves the same factor of 32 over
+// the reference's own comparison error plus this evaluation error (<= 2^-20 max(M, C) in all).  Requires finite inv
+// (a direction component so small that 1 / d overflows makes c infinite or NaN: such rays take the two-step form).
+RT_HD float rt_fused_mul_sub(float a, float b, float c) { return __builtin_fmaf(a, b, -c); }
+struct RtSlabFused { RtVec3 c; float cmax; };   // c = fl(e * inv) per axis, cmax = max |c_k|
+RT_HD RtSlabFused rt_slab_fused(const RtVec3& e, const RtVec3& inv) {
+  RtSlabFused f;
+  f.c = {e.x * inv.x, e.y * inv.y, e.z * inv.z};
+  f.cmax = rt_max3(fabsf(f.c.x), fabsf(f.c.y), fabsf(f.c.z));
+  return f;
+}
+RT_HD void rt_node_slab_tail_fused(const RtSlabHead& h, float nx, float fx, float ny, float fy, float nz, float fz, float T, float cmax,
+                                   bool& acc, bool& rej) {
+  const float tN2 = rt_med3(nx, ny, nz), tF2 = rt_med3(fx, fy, fz);
+  const float M = rt_max3(rt_max3(fx, fy, fz), -rt_min3(nx, ny, nz), cmax);
+  const float E = RT_SLAB_EPS * (M + T);
+  const float gap = h.front ? h.tN - tN2 : tF2 - h.tF;
+  acc = fminf(rt_min3(h.x, gap, h.span), h.tc) > E;
+  rej = h.r < -E;
+}
+// (near, far) planes per axis already in the order the ray meets them
+RT_HD void rt_node_slab_presorted_fused(float nxp, float fxp, float nyp, float fyp, float nzp, float fzp, const RtVec3& inv,
+                                        const RtSlabFused& f, float T, bool& acc, bool& rej) {
+  const float nx = rt_fused_mul_sub(nxp, inv.x, f.c.x), fx = rt_fused_mul_sub(fxp, inv.x, f.c.x);
+  const float ny = rt_fused_mul_sub(nyp, inv.y, f.c.y), fy = rt_fused_mul_sub(fyp, inv.y, f.c.y);
+  const float nz = rt_fused_mul_sub(nzp, inv.z, f.c.z), fz = rt_fused_mul_sub(fzp, inv.z, f.c.z);
+  const RtSlabHead h = rt_node_slab_head(nx, fx, ny, fy, nz, fz, T);
+  rt_node_slab_tail_fused(h, nx, fx, ny, fy, nz, fz, T, f.cmax, acc, rej);
+}
+// Bound of that margin over every node inside the cube (lo, hi) and every T <= T0 (see rt_slab_margin_bound).
+RT_HD float rt_slab_margin_bound_fused(float lox, float hix, float loy, float hiy, float loz, float hiz, const RtVec3& e, const RtVec3& inv,
+                                       const RtSlabFused& f, float T0) {
+  // |fl(p * inv - c)| <= the larger of the two-step bound and ... the fused distances of the enclosing cube's planes bound
+  // those of every plane between them (rounding is monotone), and cmax is part of every node's margin
+  const float mx = fmaxf(fabsf(rt_fused_mul_sub(lox, inv.x, f.c.x)), fabsf(rt_fused_mul_sub(hix, inv.x, f.c.x)));
+  const float my = fmaxf(fabsf(rt_fused_mul_sub(loy, inv.y, f.c.y)), fabsf(rt_fused_mul_sub(hiy, inv.y, f.c.y)));
+  const float mz = fmaxf(fabsf(rt_fused_mul_sub(loz, inv.z, f.c.z)), fabsf(rt_fused_mul_sub(hiz, inv.z, f.c.z)));
+  (void)e;
+  return RT_SLAB_EPS * (fmaxf(rt_max3(mx, my, mz), f.cmax) + T0);
+}
 // The same again when the caller already knows which plane of each axis is the near one (n*: the plane the ray meets
 // first, i.e. the low one for a positive direction component): (plane - e) * inv is monotone in the plane, so the two
 // products come out ordered and min / max are not needed.  With an infinite inv a product can be NaN where min / max

@@ -19,7 +19,7 @@
 #include "../include/rt_amd.h"
 #include "../raytracer_amd/csrc/rt_math.h"
 
-static uint64_t n_node = 0, n_tri = 0, n_bad = 0, n_cand = 0, n_acc = 0, n_zero = 0, n_amb = 0, n_zero_axis = 0, n_quick = 0;
+static uint64_t n_node = 0, n_tri = 0, n_bad = 0, n_cand = 0, n_acc = 0, n_zero = 0, n_amb = 0, n_zero_axis = 0, n_quick = 0, n_fused = 0, n_fused_und = 0;
 
 static bool check_node(const RtVec3& ini, const RtVec3& end, const RtVec3& e, const RtVec3& d, float T) {
   const bool lit = rt_node_accept_literal(ini, end, e, d, T);
@@ -96,6 +96,25 @@ static bool check_node(const RtVec3& ini, const RtVec3& end, const RtVec3& e, co
         n_bad++;
       }
       if (in_root && b_root < b_self) { if (n_bad < 10) printf("ROOT MARGIN BELOW NODE MARGIN\n"); n_bad++; }
+      // the form on fused plane distances (one multiply-add per plane): may abstain, never contradict; its early rejection
+      // against the root's bound may only fire where its full form rejects
+      if (std::isfinite(inv.x) && std::isfinite(inv.y) && std::isfinite(inv.z)) {
+        const RtSlabFused fu = rt_slab_fused(e, inv);
+        bool ua, ur;
+        rt_node_slab_presorted_fused(d.x < 0 ? hi.x : lo.x, d.x < 0 ? lo.x : hi.x, d.y < 0 ? hi.y : lo.y, d.y < 0 ? lo.y : hi.y,
+                                     d.z < 0 ? hi.z : lo.z, d.z < 0 ? lo.z : hi.z, inv, fu, T, ua, ur);
+        n_fused++; n_fused_und += !ua && !ur;
+        if ((ua && !lit) || (ur && lit)) {
+          if (n_bad < 10) printf("FUSED SLAB CONTRADICTION acc %d rej %d lit %d e %.9g %.9g %.9g d %.9g %.9g %.9g T %.9g\n", (int)ua, (int)ur, (int)lit, e.x, e.y, e.z, d.x, d.y, d.z, T);
+          n_bad++;
+        }
+        const float un = rt_fused_mul_sub(d.x < 0 ? hi.x : lo.x, inv.x, fu.c.x), uf = rt_fused_mul_sub(d.x < 0 ? lo.x : hi.x, inv.x, fu.c.x);
+        const float vn = rt_fused_mul_sub(d.y < 0 ? hi.y : lo.y, inv.y, fu.c.y), vf = rt_fused_mul_sub(d.y < 0 ? lo.y : hi.y, inv.y, fu.c.y);
+        const float wn = rt_fused_mul_sub(d.z < 0 ? hi.z : lo.z, inv.z, fu.c.z), wf = rt_fused_mul_sub(d.z < 0 ? lo.z : hi.z, inv.z, fu.c.z);
+        const RtSlabHead hf = rt_node_slab_head(un, uf, vn, vf, wn, wf, T);
+        const float fb_root = rt_slab_margin_bound_fused(-16.f, 16.f, -16.f, 16.f, -16.f, 16.f, e, inv, fu, 64.f);
+        if (T <= 64.f && in_root && hf.r < -fb_root && !ur) { if (n_bad < 10) printf("FUSED EARLY REJECTION WITHOUT REJECTION\n"); n_bad++; }
+      }
     }
     if ((cls > 0 && !lit) || (cls < 0 && lit)) {
       if (n_bad < 10) printf("SLAB CONTRADICTION cls %d lit %d ini %.9g %.9g %.9g end %.9g %.9g %.9g e %.9g %.9g %.9g d %.9g %.9g %.9g T %.9g\n", cls, lit,
@@ -195,7 +214,7 @@ static int run_scene(int ac, char** av) {
       trace(T, {P.x + ls[k].x * 0.001f, P.y + ls[k].y * 0.001f, P.z + ls[k].z * 0.001f}, ls[k], sh);
     }
   }
-  printf("checked %llu %llu mismatches %llu candidates %llu score_zero %llu slab_undecided %llu zero_axis_tests %llu early_rejections %llu\n", (unsigned long long)n_node, (unsigned long long)n_tri, (unsigned long long)n_bad, (unsigned long long)n_cand, (unsigned long long)n_zero, (unsigned long long)n_amb, (unsigned long long)n_zero_axis, (unsigned long long)n_quick);
+  printf("checked %llu %llu mismatches %llu candidates %llu score_zero %llu slab_undecided %llu zero_axis_tests %llu early_rejections %llu fused %llu fused_undecided %llu\n", (unsigned long long)n_node, (unsigned long long)n_tri, (unsigned long long)n_bad, (unsigned long long)n_cand, (unsigned long long)n_zero, (unsigned long long)n_amb, (unsigned long long)n_zero_axis, (unsigned long long)n_quick, (unsigned long long)n_fused, (unsigned long long)n_fused_und);
   return n_bad ? 1 : 0;
 }
 
@@ -238,7 +257,7 @@ static int run_random(int ac, char** av) {
     }
     check_node(ini, end, e, d, T);
   }
-  printf("checked %llu %llu mismatches %llu accepted %llu score_zero %llu slab_undecided %llu zero_axis_tests %llu early_rejections %llu\n", (unsigned long long)n_node, (unsigned long long)n_tri, (unsigned long long)n_bad, (unsigned long long)n_acc, (unsigned long long)n_zero, (unsigned long long)n_amb, (unsigned long long)n_zero_axis, (unsigned long long)n_quick);
+  printf("checked %llu %llu mismatches %llu accepted %llu score_zero %llu slab_undecided %llu zero_axis_tests %llu early_rejections %llu fused %llu fused_undecided %llu\n", (unsigned long long)n_node, (unsigned long long)n_tri, (unsigned long long)n_bad, (unsigned long long)n_acc, (unsigned long long)n_zero, (unsigned long long)n_amb, (unsigned long long)n_zero_axis, (unsigned long long)n_quick, (unsigned long long)n_fused, (unsigned long long)n_fused_und);
   return n_bad ? 1 : 0;
 }
 

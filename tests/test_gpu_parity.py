@@ -35,8 +35,17 @@ def _check_scene(name, w, h, depth=3, base_dir=None):
     assert frac_ok >= 0.999, (name, frac_ok, n_diff, max_diff)
     for k in COUNTER_KEYS + ("ub_leave_level0", "ub_level_overflow", "ub_stack_overflow"):
         if name == "meshTransparentBunny" and k != "rays" and k != "shadow_rays":
-            continue   # refraction directions differ by ulps between device and glibc powf/pow: counts may drift
+            # Refraction directions differ by ulps between the device's and glibc's powf / pow / expf, so a few rays inside the
+            # glass take another path: the work counts may drift, by a bounded amount that is printed (pytest -s) and held
+            # here (measured drift: a few units in 10^5; the bound is 0.2 %, or 4 events for the two rare-event counters).
+            drift = abs(st[k] - oct_[k])
+            print("%s %dx%d %s: device %d oracle %d drift %d" % (name, w, h, k, st[k], oct_[k], drift))
+            assert drift <= max(4, 0.002 * oct_[k]), (name, k, st[k], oct_[k])
+            continue
         assert st[k] == oct_[k], (name, k, st[k], oct_[k])
+    if name == "meshTransparentBunny":
+        print("%s %dx%d: %d of %d pixels differ from the oracle (largest difference %d)" % (name, w, h, n_diff, w * h, max_diff))
+        assert n_diff <= 0.001 * w * h
     # production variant (shadow rays stop at the first occluder, one shadow ray per hit point and light):
     # same image, same count of reference rays, fewer traversals
     rgb2, ids2, ts2, st2 = ds.render_host()
@@ -408,3 +417,30 @@ def test_gather_and_unpack_entry_points_with_a_world_of_one():
         assert np.array_equal(idimg.cpu().numpy(), fids)
         assert np.array_equal(rt.assemble_bands([g.cpu().numpy() for g in gathered], h, 16), full)
     comm.close()
+
+
+@pytest.mark.parametrize("name", ALL_SCENES)
+def test_against_committed_golden_fixtures(name):
+    # tests/golden/scenes_128: ids, distances, RGB and counters of the CPU oracle as rendered where the fixtures were made
+    # (tools/make_goldens.py).  The HIP path is held to them directly, and so is the oracle as built on this machine:
+    # a drift of the oracle or of the host's libm between machines shows here instead of cancelling out.
+    import json
+    import os
+    from scenes_common import HERE
+    gdir = os.path.join(HERE, "golden", "scenes_128")
+    with open(os.path.join(gdir, "manifest.json")) as f:
+        man = json.load(f)["scenes"][name]
+    g = np.load(os.path.join(gdir, name + ".npz"))
+    w, h, depth = man["width"], man["height"], man["depth"]
+    rgb, ids, ts, st = rt.DeviceScene(rt.Scene("scenes/%s.json" % name, w, h, depth)).render_host(flags=rt.RT_RENDER_COUNT_TESTS)
+    assert np.array_equal(ids, g["ids"]), "primary hit ids differ from the fixture on %d pixels" % int((ids != g["ids"]).sum())
+    assert np.array_equal(ts.view(np.uint32), g["t_bits"]), "primary hit distances differ from the fixture"
+    frac_ok, n_diff, max_diff = _rgb_close(rgb, g["rgb"])
+    assert frac_ok >= 0.999, (name, frac_ok, n_diff, max_diff)
+    if name != "meshTransparentBunny":
+        for k in COUNTER_KEYS:
+            assert st[k] == man["counters"][k], (name, k, st[k], man["counters"][k])
+    orgb, oids, ots, oct_ = OracleScene("scenes/%s.json" % name, w, h, depth).render(threads=8)
+    assert np.array_equal(oids, g["ids"]) and np.array_equal(ots.view(np.uint32), g["t_bits"]), "the oracle built here left its fixture"
+    o_ok, o_diff, o_max = _rgb_close(orgb, g["rgb"])
+    assert o_ok >= 0.999, ("oracle vs fixture", name, o_diff, o_max)

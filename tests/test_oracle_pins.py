@@ -57,3 +57,26 @@ def test_dragon_4k_frame_digest_and_counters():
     for k in COUNTER_KEYS:
         assert ct[k] == exp[k], k
     assert hashlib.sha256(rgb.tobytes()).hexdigest() == exp["rgb_sha256"]
+
+
+def test_oracle_reproduces_the_committed_scene_fixtures():
+    # tests/golden/scenes_128 (tools/make_goldens.py): the oracle of this checkout, built with this machine's compiler and
+    # libm, against the arrays committed with the repository - ids, distance bits, RGB bytes and counters, all exact here
+    # (the fixtures were made in this container image).
+    import json
+    import os
+    import numpy as np
+    from oracle_api import OracleScene
+    from scenes_common import ALL_SCENES, HERE
+    gdir = os.path.join(HERE, "golden", "scenes_128")
+    with open(os.path.join(gdir, "manifest.json")) as f:
+        man = json.load(f)
+    assert sorted(man["scenes"]) == sorted(ALL_SCENES)
+    for name, m in man["scenes"].items():
+        g = np.load(os.path.join(gdir, name + ".npz"))
+        rgb, ids, ts, ct = OracleScene("scenes/%s.json" % name, m["width"], m["height"], m["depth"]).render(threads=8)
+        assert np.array_equal(ids, g["ids"]) and np.array_equal(ts.view(np.uint32), g["t_bits"]), name
+        assert np.array_equal(rgb, g["rgb"]), (name, int((rgb != g["rgb"]).sum()))
+        assert ct == m["counters"], (name, ct, m["counters"])
+        import hashlib
+        assert hashlib.sha256(np.ascontiguousarray(g["rgb"]).tobytes()).hexdigest() == m["sha256"]["rgb"]

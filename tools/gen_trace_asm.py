@@ -1,0 +1,296 @@
+#!/usr/bin/env python3
+"""Writes raytracer_amd/csrc/rt_trace_asm.inc: the octree walk of a wave whose rays agree on their direction signs, as ONE
+block of gfx950 assembly (scan of a branch's children, descent, ascent, leaf loop with the three numerator stages of the
+triangle test).  The block is generated because the triangle stages exist twice (two sets of record registers filled in
+turn) and every register is named explicitly; rt_kernel_wave.hip includes the result and documents the register map.
+
+   python3 tools/gen_trace_asm.py        (from the repository root; the output is checked in)
+"""
+import os
+
+# ---- scalar registers owned by the block (see RT_TRACE_* operand list in rt_kernel_wave.hip) ----
+TA, TB = 36, 52                  # s[36:51], s[52:67]: two triangle records (RtTriLeaf, 16 words)
+BLK = "s[68:69]"                 # address of the current branch's children
+REM, FIRST = "s70", "s71"        # children still to test (bit 8 always set: "child 8" is the record behind the block), index of child 0
+TMASK, MINE, LIVE = "s[72:73]", "s[74:75]", "s[76:77]"
+IDX, RFIRST, RMETA = "s78", "s79", "s80"   # child whose record is in (or on its way into) NX; links of the child just tested
+NODES = ("s82", "s83")
+OFF = "s81"
+NX = 84                          # s[84:91]: node record
+TRI = ("s92", "s93")
+ACC, UND, NR = "s[94:95]", "s[96:97]", "s[98:99]"
+TP = ("s20", "s21")              # next triangle record
+K = "s22"                        # triangles of the leaf still to test
+SIGN = "s23"                     # 0x80000000
+CHG, T64, PASS = "s[24:25]", "s[26:27]", "s[28:29]"
+RES, RPRIM = "s30", "s31"
+
+# ---- vector registers ----
+E_XY, EZ = "v[40:41]", "v42"
+C_ZX, C_YZ, C_YX = "v[44:45]", "v[46:47]", "v[48:49]"
+C2X, C2Y, C2Z = "v45", "v46", "v44"
+IX, IY, IZ, FCX, FCY, FCZ, CMAX, NEB, T, STOP = "v50", "v51", "v52", "v53", "v54", "v55", "v56", "v57", "v58", "v59"
+ST_FIRST, ST_CUR, ST_LO, ST_HI = "v60", "v61", "v62", "v63"
+
+
+def s(n):
+    return "s%d" % n
+
+
+def s2(n):
+    return "s[%d:%d]" % (n, n + 1)
+
+
+def scan():
+    t = ["v%d" % (64 + i) for i in range(6)]
+    tn, tf, span, tc, x, r = "v70", "v71", "v72", "v73", "v74", "v75"
+    L = []
+    # (scalar loads return out of order: before a record is requested into registers that an earlier request - the sibling
+    #  behind the one that was accepted, the triangle behind a leaf's last - may still be on its way into, that one is awaited)
+    L += ["LT_enter_%=:",
+          "s_ff1_i32_b32 %s, %s" % (IDX, REM),
+          "s_lshl_b32 %s, %s, 5" % (OFF, IDX),
+          "s_waitcnt lgkmcnt(0)",
+          "s_load_dwordx8 s[84:91], %s, %s" % (BLK, OFF),
+          "LT_scan_%=:",
+          "s_bitset0_b32 %s, %s" % (REM, IDX),
+          "s_waitcnt lgkmcnt(0)"]
+    for i, (inv, fc) in enumerate(((IX, FCX), (IX, FCX), (IY, FCY), (IY, FCY), (IZ, FCZ), (IZ, FCZ))):
+        L.append("v_fma_f32 %s, %s, %s, -%s" % (t[i], s(NX + i), inv, fc))
+    L += ["s_mov_b32 %s, %s" % (RFIRST, s(NX + 6)),
+          "s_mov_b32 %s, %s" % (RMETA, s(NX + 7)),
+          "s_ff1_i32_b32 %s, %s" % (IDX, REM),
+          "s_lshl_b32 %s, %s, 5" % (OFF, IDX),
+          "s_load_dwordx8 s[84:91], %s, %s" % (BLK, OFF),
+          "v_max3_f32 %s, %s, %s, %s" % (tn, t[0], t[2], t[4]),
+          "v_min3_f32 %s, %s, %s, %s" % (tf, t[1], t[3], t[5]),
+          "v_cmp_lt_f32 vcc, 0, %s" % tn,
+          "v_sub_f32 %s, %s, %s" % (span, tf, tn),
+          "v_cndmask_b32 %s, %s, %s, vcc" % (tc, tf, tn),
+          "v_sub_f32 %s, %s, %s" % (x, T, tc),
+          "v_min3_f32 %s, %s, %s, %s" % (r, span, tf, x),
+          "v_cmp_lt_f32_e64 %s, %s, %s" % (NR, r, NEB),
+          "s_andn2_b64 %s, %s, %s" % (NR, MINE, NR),
+          "s_cbranch_scc1 LT_tail_%=",
+          "LT_next_%=:",
+          "s_cmp_lt_u32 %s, 8" % IDX,
+          "s_cbranch_scc1 LT_scan_%=",
+          # ---- the branch is exhausted: back to the youngest entry of the stack that still has undecided rays
+          "LT_pop_%=:",
+          "s_cmp_eq_u32 m0, 0",
+          "s_cbranch_scc1 LT_done_%=",
+          "s_add_u32 m0, m0, -1",
+          "s_nop 1",
+          "v_readlane_b32 %s, %s, m0" % (FIRST, ST_FIRST),
+          "v_readlane_b32 %s, %s, m0" % (REM, ST_CUR),
+          "v_readlane_b32 s72, %s, m0" % ST_LO,
+          "v_readlane_b32 s73, %s, m0" % ST_HI,
+          "s_nop 0",
+          "s_and_b64 %s, %s, %s" % (MINE, TMASK, LIVE),
+          "s_cbranch_scc0 LT_pop_%=",
+          "s_lshl_b32 %s, %s, 5" % (OFF, FIRST),
+          "s_add_u32 s68, %s, %s" % (NODES[0], OFF),
+          "s_addc_u32 s69, %s, 0" % NODES[1],
+          "s_branch LT_enter_%=",
+          # ---- some ray of the branch may hit the child: margin and acceptance (rt_node_slab_tail_fused)
+          "LT_tail_%=:",
+          "v_med3_f32 v76, %s, %s, %s" % (t[0], t[2], t[4]),
+          "v_med3_f32 v77, %s, %s, %s" % (t[1], t[3], t[5]),
+          "v_min3_f32 v78, %s, %s, %s" % (t[0], t[2], t[4]),
+          "v_max3_f32 v79, %s, %s, %s" % (t[1], t[3], t[5]),
+          "v_max3_f32 v78, v79, -v78, %s" % CMAX,
+          "v_add_f32 v78, v78, %s" % T,
+          "v_mul_f32 v78, 0x37000000, v78",
+          "v_sub_f32 v76, %s, v76" % tn,
+          "v_sub_f32 v77, v77, %s" % tf,
+          "v_cndmask_b32 v76, v77, v76, vcc",
+          "v_min3_f32 v76, %s, v76, %s" % (x, span),
+          "v_min_f32 v76, v76, %s" % tc,
+          "v_cmp_gt_f32_e64 %s, v76, v78" % ACC,
+          "v_cmp_lt_f32_e64 %s, %s, -v78" % (UND, r),
+          "s_and_b64 %s, %s, %s" % (ACC, ACC, MINE),
+          "s_or_b64 %s, %s, %s" % (UND, UND, ACC),
+          "s_andn2_b64 %s, %s, %s" % (UND, MINE, UND),
+          "s_cbranch_scc1 LT_exit_exact_%=",
+          "LT_after_exact_%=:",
+          "s_cmp_eq_u64 %s, 0" % ACC,
+          "s_cbranch_scc1 LT_next_%=",
+          "s_bitcmp1_b32 %s, 31" % RMETA,
+          "s_cbranch_scc0 LT_leaf_%=",
+          # ---- a branch: its children become the current block; the parent is kept only if it has children left
+          "s_and_b32 %s, %s, 0xff" % (OFF, RMETA),
+          "s_cbranch_scc0 LT_next_%=",
+          "s_cmp_lt_u32 %s, 8" % IDX,
+          "s_cbranch_scc0 LT_nopush_%=",
+          "v_writelane_b32 %s, %s, m0" % (ST_FIRST, FIRST),
+          "v_writelane_b32 %s, %s, m0" % (ST_CUR, REM),
+          "v_writelane_b32 %s, s72, m0" % ST_LO,
+          "v_writelane_b32 %s, s73, m0" % ST_HI,
+          "s_add_u32 m0, m0, 1",
+          "LT_nopush_%=:",
+          "s_mov_b32 %s, %s" % (FIRST, RFIRST),
+          "s_or_b32 %s, %s, 0x100" % (REM, OFF),
+          "s_mov_b64 %s, %s" % (TMASK, ACC),
+          "s_mov_b64 %s, %s" % (MINE, ACC),
+          "s_lshl_b32 %s, %s, 5" % (OFF, RFIRST),
+          "s_add_u32 s68, %s, %s" % (NODES[0], OFF),
+          "s_addc_u32 s69, %s, 0" % NODES[1],
+          "s_branch LT_enter_%="]
+    return L
+
+
+def triangle(q, other, tag, next_off):
+    """The numerator stages on the record in s[q : q+15]; midway the record at TP + next_off is requested into s[other : other+15]."""
+    bxy, bz = "v[68:69]", "v74"
+    bx, by = "v68", "v69"
+    det, nb, nbs, ng, nt, sg = "v32", "v33", "v34", "v35", "v36", "v39"
+    L = ["LT_tri%s_%%=:" % tag,
+         "s_waitcnt lgkmcnt(0)",
+         # stage 1: determinant and beta numerator (triangle.cu:117-131), operations paired two to an instruction
+         "v_pk_mul_f32 v[64:65], %s, %s" % (C_ZX, s2(q + 10)),                                  # e2.y c2.z , e2.z c2.x
+         "v_pk_mul_f32 v[66:67], %s, %s neg_lo:[0,1] neg_hi:[0,1]" % (C_YZ, s2(q + 12)),       # -(e2.z c2.y) , -(e2.x c2.z)
+         "v_pk_add_f32 %s, %s, %s neg_lo:[0,1] neg_hi:[0,1]" % (bxy, E_XY, s2(q + 0)),         # e.xy - v0.xy
+         "v_pk_add_f32 v[70:71], v[64:65], v[66:67]",                                            # m00 , m10
+         "v_pk_mul_f32 v[72:73], %s, %s" % (C_YX, s2(q + 8)),                                   # e2.x c2.y , e2.y c2.x
+         "v_subrev_f32 %s, %s, %s" % (bz, s(q + 2), EZ),                                        # e.z - v0.z
+         "v_sub_f32 v75, v72, v73",                                                              # m20
+         "v_pk_mul_f32 v[76:77], %s, v[70:71]" % s2(q + 4),                                     # e1.x m00 , e1.y m10
+         "v_pk_mul_f32 v[78:79], %s, v[70:71]" % bxy,                                           # b.x m00 , b.y m10
+         "v_add_f32 v76, v76, v77",
+         "v_mul_f32 v77, %s, v75" % s(q + 6),                                                   # e1.z m20
+         "s_load_dwordx16 s[%d:%d], s[20:21], %s" % (other, other + 15, hex(next_off)),
+         "v_add_f32 %s, v76, v77" % det,
+         "v_add_f32 v78, v78, v79",
+         "v_mul_f32 v79, v75, %s" % bz,                                                         # m20 b.z
+         "v_add_f32 %s, v78, v79" % nb,
+         "v_bitop3_b32 %s, %s, %s, %s bitop3:0x6c" % (nbs, det, nb, SIGN),                     # nb with the determinant's sign folded in
+         "v_cmp_le_f32 vcc, 0, %s" % nbs,
+         "v_cmp_ge_f32_e64 %s, |%s|, %s" % (PASS, det, nbs),
+         "s_and_b64 %s, %s, vcc" % (PASS, PASS),
+         "s_and_b64 %s, %s, %s" % (PASS, PASS, ACC),
+         "s_cbranch_scc0 LT_end%s_%%=" % tag,
+         # stage 2: gamma numerator
+         "v_mul_f32 v37, %s, %s" % (s(q + 6), C2Y),
+         "v_mul_f32 v38, %s, %s" % (s(q + 5), C2Z),
+         "v_sub_f32 v37, v37, v38",                                                              # m01
+         "v_mul_f32 v38, %s, %s" % (s(q + 4), C2Z),
+         "v_mul_f32 %s, %s, %s" % (sg, s(q + 6), C2X),
+         "v_sub_f32 v38, v38, %s" % sg,                                                          # m11
+         "v_mul_f32 %s, %s, %s" % (sg, s(q + 5), C2X),
+         "v_mul_f32 %s, %s, %s" % (ng, s(q + 4), C2Y),
+         "v_sub_f32 %s, %s, %s" % (sg, sg, ng),                                                  # m21
+         "v_mul_f32 v37, v37, %s" % bx,
+         "v_mul_f32 v38, v38, %s" % by,
+         "v_add_f32 v37, v37, v38",
+         "v_mul_f32 v38, %s, %s" % (sg, bz),
+         "v_add_f32 %s, v37, v38" % ng,
+         "v_and_b32 %s, 0x80000000, %s" % (sg, det),
+         "v_xor_b32 v38, %s, %s" % (sg, ng),
+         "v_cmp_le_f32 vcc, 0, v38",
+         "v_cmp_ge_f32_e64 %s, |%s|, v38" % (T64, det),
+         "s_and_b64 %s, %s, vcc" % (T64, T64),
+         "s_and_b64 %s, %s, %s" % (PASS, PASS, T64),
+         "s_cbranch_scc0 LT_end%s_%%=" % tag,
+         # stage 3: t numerator from the record's e1 x e2; t > 0, and t clearly beyond the closest hit is rejected without dividing
+         "v_mul_f32 v37, %s, %s" % (s(q + 7), bx),
+         "v_mul_f32 v38, %s, %s" % (s(q + 14), by),
+         "v_add_f32 v37, v37, v38",
+         "v_mul_f32 v38, %s, %s" % (s(q + 15), bz),
+         "v_add_f32 %s, v37, v38" % nt,
+         "v_xor_b32 v38, %s, %s" % (sg, nt),
+         "v_mul_f32_e64 v37, %s, |%s|" % (T, det),
+         "v_mul_f32 v37, 0x3f800008, v37",
+         "v_cmp_lt_f32 vcc, 0, v38",
+         "v_cmp_ge_f32_e64 %s, v37, v38" % T64,
+         "s_and_b64 %s, %s, vcc" % (T64, T64),
+         "s_and_b64 %s, %s, %s" % (PASS, PASS, T64),
+         "s_cbranch_scc0 LT_end%s_%%=" % tag,
+         # candidates: the quotients are formed outside; the walk goes on behind this record
+         "s_mov_b32 %s, %s" % (RPRIM, s(q + 3)),
+         "s_add_u32 s20, s20, 0x40",
+         "s_addc_u32 s21, s21, 0",
+         "s_add_u32 %s, %s, -1" % (K, K),
+         "s_mov_b32 %s, 2" % RES,
+         "s_branch LT_out_%=",
+         "LT_end%s_%%=:" % tag]
+    return L
+
+
+def leaf():
+    L = ["LT_leaf_%=:",
+         "s_and_b32 %s, %s, 0xff" % (K, RMETA),
+         "s_cbranch_scc0 LT_next_%=",
+         "s_lshl_b32 %s, %s, 6" % (OFF, RFIRST),
+         "s_add_u32 s20, %s, %s" % (TRI[0], OFF),
+         "s_addc_u32 s21, %s, 0" % TRI[1],
+         "s_mov_b64 %s, 0" % CHG,
+         "LT_leaf_load_%=:",
+         "s_waitcnt lgkmcnt(0)",
+         "s_load_dwordx16 s[%d:%d], s[20:21], 0x0" % (TA, TA + 15)]
+    L += triangle(TA, TB, "A", 0x40)
+    L += ["s_add_u32 %s, %s, -1" % (K, K),
+          "s_cmp_eq_u32 %s, 0" % K,
+          "s_cbranch_scc1 LT_leaf_done_%="]
+    # the record in TB sits at TP + 0x40: move TP there, so that both halves (and the exit to the quotients) see "TP = this record"
+    L += ["s_add_u32 s20, s20, 0x40",
+          "s_addc_u32 s21, s21, 0"]
+    L += triangle(TB, TA, "B", 0x40)
+    L += ["s_add_u32 s20, s20, 0x40",
+          "s_addc_u32 s21, s21, 0",
+          "s_add_u32 %s, %s, -1" % (K, K),
+          "s_cmp_eq_u32 %s, 0" % K,
+          "s_cbranch_scc0 LT_triA_%=",
+          "LT_leaf_done_%=:",
+          "s_cmp_eq_u64 %s, 0" % CHG,
+          "s_cbranch_scc1 LT_next_%=",
+          # some ray's closest hit moved: shadow rays that are now known to be occluded drop out (ray.cu:70)
+          "v_cmp_le_f32 vcc, 0, %s" % STOP,
+          "v_cmp_lt_f32_e64 %s, %s, %s" % (T64, T, STOP),
+          "s_and_b64 %s, %s, vcc" % (T64, T64),
+          "s_andn2_b64 %s, %s, %s" % (LIVE, LIVE, T64),
+          "s_cbranch_scc0 LT_done_%=",
+          "s_and_b64 %s, %s, %s" % (MINE, TMASK, LIVE),
+          "s_cbranch_scc1 LT_next_%=",
+          "s_branch LT_pop_%="]
+    return L
+
+
+def main():
+    L = ["s_waitcnt lgkmcnt(0)",
+         "s_cmp_eq_u32 %s, 1" % RES,
+         "s_cbranch_scc1 LT_resume_exact_%=",
+         "s_cmp_eq_u32 %s, 2" % RES,
+         "s_cbranch_scc1 LT_resume_finish_%="]
+    L += scan()
+    L += leaf()
+    L += [# ---- re-entries: the record of the next sibling is requested again (its registers were not kept outside)
+          "LT_resume_exact_%=:",
+          "s_lshl_b32 %s, %s, 5" % (OFF, IDX),
+          "s_load_dwordx8 s[84:91], %s, %s" % (BLK, OFF),
+          "s_branch LT_after_exact_%=",
+          "LT_resume_finish_%=:",
+          "s_lshl_b32 %s, %s, 5" % (OFF, IDX),
+          "s_load_dwordx8 s[84:91], %s, %s" % (BLK, OFF),
+          "s_or_b64 %s, %s, %s" % (CHG, CHG, PASS),
+          "s_cmp_eq_u32 %s, 0" % K,
+          "s_cbranch_scc1 LT_leaf_done_%=",
+          "s_branch LT_leaf_load_%=",
+          "LT_exit_exact_%=:",
+          "s_mov_b32 %s, 1" % RES,
+          "s_branch LT_out_%=",
+          "LT_done_%=:",
+          "s_mov_b32 %s, 0" % RES,
+          "LT_out_%=:",
+          "s_waitcnt lgkmcnt(0)"]
+    # In the second half the record sits at TP (TP was moved), so the exit to the quotients must not skip one more: both
+    # halves add 0x40 ("the record behind this one") - correct for either, because TP names the record under test in both.
+    out = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "raytracer_amd", "csrc", "rt_trace_asm.inc")
+    with open(out, "w") as f:
+        f.write("// Generated by tools/gen_trace_asm.py - do not edit.  Register map and operands: rt_kernel_wave.hip (trace_wave).\n")
+        for line in L:
+            f.write('"%s\\n"\n' % line)
+    print("wrote", os.path.normpath(out), len(L), "lines")
+
+
+if __name__ == "__main__":
+    main()
