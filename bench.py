@@ -49,18 +49,20 @@ def parse_args():
     return ap.parse_args()
 
 
-def measured_traffic(version):
-    """HBM bytes per launch from the committed rocprofv3 counter passes (profiles/r*_hbm_traffic.json), if they
-    were taken with this very library version; the counters cannot be read from inside the benchmark."""
+def committed_counters(source_sha256):
+    """The rocprofv3 counter passes committed under profiles/ (r*_counters.json, tools/profile_to_json.py), if they were
+    taken with exactly the kernel sources that are running now (digest of the source files recorded in the profile);
+    hardware counters cannot be read from inside the benchmark, and numbers of other code are not quoted: None then."""
     import glob
-    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_hbm_traffic.json")), reverse=True):
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_counters.json")), reverse=True):
         try:
             with open(path) as f:
                 j = json.load(f)
         except (OSError, ValueError):
             continue
-        if j.get("library") == version:
-            return j.get("traffic_bytes_per_launch")
+        if j.get("source_sha256") == source_sha256:
+            j["file"] = os.path.relpath(path, ROOT)
+            return j
     return None
 
 
@@ -147,20 +149,25 @@ def main():
     # into the second tile while frame k finishes and is gathered.  One GPU: one stream, launches back to back.
     streams = [torch.cuda.current_stream()] + [torch.cuda.Stream(device=dev) for _ in range(in_flight - 1)]
     stream = streams[0]
-    # one uploaded scene per stream: renders of one rt_dscene must not overlap (it owns one set of counters and queues)
-    scenes = [ds] + [rt.DeviceScene(scene, device=local_rank) for _ in range(in_flight - 1)]
+    # one render context per stream on the one uploaded scene (renders of one rt_dscene must not overlap: it owns one set
+    # of counters and queues)
+    scenes = [ds] + [ds.fork() for _ in range(in_flight - 1)]
     # frames in flight fill the chip between them: the tiles of every launch go to the dies in strips whatever their number
     pipeline_flags = rt.RT_RENDER_STRIPS if two_deep else 0
 
-    def step(k, flags=0, want_stats=False):
-        b = k % len(local)
+    def step(k, flags=0, want_stats=False, events=None, n_slots=None):
+        b = k % (n_slots or len(local))
         sk = streams[b % len(streams)]
         with torch.cuda.stream(sk):
             if pending[b] is not None:
                 pending[b].wait()          # the render stream waits for the gather that last read this tile
                 pending[b] = None
+            if events:
+                events[0].record(sk)
             st = scenes[b % len(scenes)].render_bands_into(local[b].data_ptr(), BAND_ROWS, part_rank, part_world, stream=sk.cuda_stream,
                                                            flags=flags | pipeline_flags, want_stats=want_stats)
+            if events:
+                events[1].record(sk)
             if dist_on:
                 pending[b] = dist.gather(local[b], gathered[b] if rank == 0 else None, dst=0, async_op=True)
         return st
@@ -179,38 +186,39 @@ def main():
         dist.all_reduce(rays_t)
     rays_total, shadow_total = int(rays_t[0]), int(rays_t[1])
 
+    def timed(steps, one_at_a_time):
+        """`steps` frames between barriers.  one_at_a_time: a frame is only launched when the one before it has landed on
+        rank 0 (its window is first launch -> last tile in place); otherwise frames are kept in flight as configured.
+        Returns (seconds, mean HIP-event duration of the render launches in ms), both the maximum over the ranks."""
+        ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(steps)]
+        if dist_on:
+            dist.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for k in range(steps):
+            step(k, events=ev[k], n_slots=1 if one_at_a_time else None)
+            if one_at_a_time and dist_on:
+                drain()
+                torch.cuda.synchronize()
+        drain()
+        torch.cuda.synchronize()
+        if dist_on:
+            dist.barrier()
+        elapsed = time.perf_counter() - t0
+        kernel_ms = sum(a.elapsed_time(b) for a, b in ev) / max(steps, 1)
+        tt = torch.tensor([elapsed, kernel_ms], dtype=torch.float64, device=dev)
+        if dist_on:
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        return float(tt[0]), float(tt[1])
+
     for k in range(args.warmup):
         step(k)
     drain()
-    # The kernel's own duration: HIP events around the launch, on the stream it is launched on.
-    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
-    if dist_on:
-        dist.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for k in range(args.steps):
-        b = k % len(local)
-        sk = streams[b % len(streams)]
-        with torch.cuda.stream(sk):
-            if pending[b] is not None:
-                pending[b].wait()
-                pending[b] = None
-            ev[k][0].record(sk)
-            scenes[b % len(scenes)].render_bands_into(local[b].data_ptr(), BAND_ROWS, part_rank, part_world, stream=sk.cuda_stream,
-                                                      flags=pipeline_flags)
-            ev[k][1].record(sk)
-            if dist_on:
-                pending[b] = dist.gather(local[b], gathered[b] if rank == 0 else None, dst=0, async_op=True)
-    drain()
-    torch.cuda.synchronize()
-    if dist_on:
-        dist.barrier()
-    elapsed = time.perf_counter() - t0
-    kernel_ms = sum(a.elapsed_time(b) for a, b in ev) / max(args.steps, 1)
-    tt = torch.tensor([elapsed, kernel_ms], dtype=torch.float64, device=dev)
-    if dist_on:
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-    elapsed, kernel_ms = float(tt[0]), float(tt[1])
+    # THE timed region: exactly `steps` frames.  One GPU: launches back to back on one stream.  Several GPUs: frames in flight.
+    elapsed, kernel_ms = timed(args.steps, one_at_a_time=False)
+    # Several GPUs: the same number of frames again, one at a time (no pipelining), so that the line carries both the
+    # throughput with frames in flight (`value`) and the time of a single frame from its first launch to its last tile on rank 0.
+    single = timed(args.steps, one_at_a_time=True) if dist_on else None
 
     if rank == 0:
         ms_per_step = elapsed * 1e3 / args.steps
@@ -243,12 +251,29 @@ def main():
             ach = flop / world / (t_ms * 1e-3) / 1e12
             # The path is neither a dense contraction nor memory-bound: the roof that binds is FP32 vector issue.  The HBM
             # view is reported beside it (hbm_*): measured bytes per launch over the same kernel time, against 8 TB/s.
+            headline = world == 1 and not share_of and W == 3840 and H == 2160 and args.scene.endswith("meshDragon.json") and args.depth == 3
+            prof = committed_counters(rt.kernel_source_sha256()) if headline else None
             roofline = {"bound": "valu_fp32", "achieved": ach, "peak": PEAK_FP32_TFLOPS, "unit": "TFLOP/s",
                         "frac": ach / PEAK_FP32_TFLOPS,
-                        "traffic": (measured_traffic(rt.version()) if (world == 1 and W == 3840 and H == 2160 and
-                                                                             args.scene.endswith("meshDragon.json")) else None),
+                        # HBM bytes per launch (FETCH_SIZE + WRITE_SIZE of the counter passes committed for exactly these kernel sources; null otherwise)
+                        "traffic": prof.get("traffic_bytes_per_launch") if prof else None,
                         "kernel": "render_wave", "kernel_ms": kernel_ms, "launches_overlap": bool(two_deep), "test_counts_from": counts_from, "flop_per_ray": flop / ref["rays"],
-                        "algorithmic_GBps": byts / world / (t_ms * 1e-3) / 1e9, "hbm_peak_GBps": PEAK_HBM_GBS}
+                        # bytes of node / triangle records the reference's tests would touch, per second: served by the scalar cache and L2
+                        # (a record is fetched once per wave, not per ray), NOT memory traffic - the HBM view is hbm_*
+                        "record_bytes_cache_level_GBps": byts / world / (t_ms * 1e-3) / 1e9, "hbm_peak_GBps": PEAK_HBM_GBS}
+            if prof:
+                # what the vector units executed, beside the algorithmic figure: FP32 add + mul + 2 x fma + transcendental wave-instructions x 64 lanes
+                c = prof.get("counters_per_launch", {})
+                roofline["counters_from"] = prof["file"]
+                roofline["executed_tflops"] = prof["executed_fp32_flop_per_launch"] / (kernel_ms * 1e-3) / 1e12
+                roofline["executed_frac"] = roofline["executed_tflops"] / PEAK_FP32_TFLOPS
+                cycles = kernel_ms * 1e-3 * 2.4e9 * 1024      # SIMD-cycles of the launch at the 2.4 GHz peak clock
+                if "SQ_INSTS_VALU" in c:
+                    roofline["valu_insts_per_launch"] = c["SQ_INSTS_VALU"]
+                    roofline["valu_issue_busy"] = c["SQ_INSTS_VALU"] * 4 / cycles      # a wave64 vector instruction holds its SIMD's issue for ~4 cycles
+                if "SQ_INSTS_SALU" in c:
+                    roofline["salu_smem_insts_per_launch"] = c["SQ_INSTS_SALU"] + c.get("SQ_INSTS_SMEM", 0)
+                    roofline["scalar_issue_busy"] = roofline["salu_smem_insts_per_launch"] * 4 / cycles   # one scalar issue per SIMD every 4 cycles
         if roofline and roofline.get("traffic"):
             roofline["hbm_achieved_GBps"] = roofline["traffic"] / ((ms_per_step if two_deep else kernel_ms) * 1e-3) / 1e9
             roofline["hbm_frac"] = roofline["hbm_achieved_GBps"] / PEAK_HBM_GBS
@@ -267,6 +292,13 @@ def main():
                        "library": rt.version()},
             "roofline": roofline,
         }
+        if single:
+            # `value` above is the throughput with frames in flight; this is one frame at a time, first launch -> last tile on rank 0
+            out["value_is"] = "throughput with %d frames in flight per GPU" % in_flight if two_deep else "frames one at a time"
+            out["single_frame"] = {"ms_per_frame_latency": single[0] * 1e3 / args.steps, "Mrays_per_s": rays_total / (single[0] / args.steps) / 1e6,
+                                   "kernel_ms": single[1]}
+        else:
+            out["value_is"] = "frames back to back on one stream (one frame in flight)"
         if world == 1 and not args.no_cpu_baseline:
             threads = min(int(os.environ.get("OMP_NUM_THREADS", "0")) or (os.cpu_count() or 1), 16)
             out["cpu_baseline"] = cpu_baseline(args, threads)

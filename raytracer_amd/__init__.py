@@ -145,6 +145,20 @@ def version():
     return lib().rt_version().decode()
 
 
+KERNEL_SOURCES = ("rt_kernel_wave.hip", "rt_trace_asm.inc", "rt_math.h", "rt_kernels.h", "rt_internal.h", "rt_device.hip")
+
+
+def kernel_source_sha256():
+    """Digest of the sources the render kernels are built from; recorded with every committed counter profile so that
+    a profile is only ever quoted for the code it was taken with."""
+    import hashlib
+    h = hashlib.sha256()
+    for name in KERNEL_SOURCES:
+        with open(os.path.join(_HERE, "csrc", name), "rb") as f:
+            h.update(name.encode() + b"\0" + f.read())
+    return h.hexdigest()
+
+
 def asset(path):
     """Resolve a path such as 'scenes/meshDragon.json' against the bundled assets directory."""
     return path if os.path.isabs(path) else os.path.join(ASSETS, path)

@@ -18,6 +18,7 @@
 // Decisions are taken with the division-free predicates of rt_math.h; quotients are formed only for
 // triangles that pass every sign / range test.  Built with -ffp-contract=off.
 #include "rt_kernels.h"
+#include "rt_trace_asm.inc"
 
 namespace {
 
@@ -180,8 +181,8 @@ __device__ __forceinline__ void trace_wave(const float4* __restrict__ nodes, int
     }
 #endif
 #ifndef RT_NO_ASM_WALK
-    // ---- The walk of a wave whose rays agree on their direction signs (nearly all primary and point-light shadow waves),
-    // as one block of assembly (rt_trace_asm.inc, written by tools/gen_trace_asm.py): scan of a branch's children with
+    // ---- The walk of a wave whose rays agree on their direction signs (nearly all primary and point-light shadow waves) or
+    // share a pattern of zero direction components (shadow rays of axis-parallel lights), as one block of assembly (rt_trace_asm.inc, written by tools/gen_trace_asm.py): scan of a branch's children with
     // fused plane distances, margin and acceptance, descent (the stack entry is one v_writelane per word, the stack
     // pointer lives in M0), ascent, and the leaf loop with the three numerator stages of the triangle test on two sets
     // of record registers filled in turn.  What the compiler makes of the same walk spends most of its scalar
@@ -199,7 +200,7 @@ __device__ __forceinline__ void trace_wave(const float4* __restrict__ nodes, int
     // (origin, negated direction in the pairs the first stage multiplies, inverse direction, e * inv, margin terms,
     // closest hit so far, shadow-ray length), v[60:63] the wave's stack, v32 v33 v35 v36 determinant and numerators
     // of a candidate, v34 v37:v39 v64:v79 scratch.
-    if (presorted && FUSED && (rem & 0xffu) != 0u) {
+    if ((presorted || zpat != 0u) && FUSED && (rem & 0xffu) != 0u) {
       uint64_t a_blk = (uint64_t)(uintptr_t)(nodes + NS * (size_t)top_first);
       uint32_t a_rem = rem | 0x100u, a_first = top_first, a_idx = 0u, a_rfirst = 0u, a_rmeta = 0u, a_k = 0u, a_res = 0u, a_prim = 0u, a_sp = 0u;
       uint64_t a_tmask = live, a_mine = live, a_live = live, a_acc = 0ull, a_und = 0ull, a_pass = 0ull, a_tp = 0ull, a_chg = 0ull;
@@ -207,15 +208,16 @@ __device__ __forceinline__ void trace_wave(const float4* __restrict__ nodes, int
       const uint32_t a_sign = 0x80000000u;
       const float cmax = rt_max3(fabsf(fc.x), fabsf(fc.y), fabsf(fc.z));
       float a_det = 0.f, a_nb = 0.f, a_ng = 0.f, a_nt = 0.f;
+      // (one copy of the block per kind of node test inside the one statement: sign-uniform rays (0), or the rays' common
+      //  zero pattern (1..6), chosen by s18)
       for (;;) {
-        asm volatile(
-#include "rt_trace_asm.inc"
+        asm volatile(RT_TRACE_ASM
             : "+{s[68:69]}"(a_blk), "+{s70}"(a_rem), "+{s71}"(a_first), "+{s[72:73]}"(a_tmask), "+{s[74:75]}"(a_mine), "+{s[76:77]}"(a_live),
               "+{s78}"(a_idx), "+{s79}"(a_rfirst), "+{s80}"(a_rmeta), "+{s[94:95]}"(a_acc), "+{s[96:97]}"(a_und), "+{s[28:29]}"(a_pass),
               "+{s[20:21]}"(a_tp), "+{s22}"(a_k), "+{s[24:25]}"(a_chg), "+{s30}"(a_res), "+{s31}"(a_prim), "+{m0}"(a_sp),
               "+{v60}"(st.first), "+{v61}"(st.cur), "+{v62}"(st.mask_lo), "+{v63}"(st.mask_hi),
               "={v32}"(a_det), "={v33}"(a_nb), "={v35}"(a_ng), "={v36}"(a_nt)
-            : "{s[82:83]}"(a_nodes), "{s[92:93]}"(a_tri), "{s23}"(a_sign), "{v[40:41]}"(e_xy), "{v42}"(e.z), "{v[44:45]}"(c_zx), "{v[46:47]}"(c_yz),
+            : "{s[82:83]}"(a_nodes), "{s[92:93]}"(a_tri), "{s23}"(a_sign), "{s18}"(zpat), "{v[40:41]}"(e_xy), "{v42}"(e.z), "{v[44:45]}"(c_zx), "{v[46:47]}"(c_yz),
               "{v[48:49]}"(c_yx), "{v50}"(inv.x), "{v51}"(inv.y), "{v52}"(inv.z), "{v53}"(fc.x), "{v54}"(fc.y), "{v55}"(fc.z), "{v56}"(cmax),
               "{v57}"(neg_eb), "{v58}"(hit.t), "{v59}"(stop_t)
             : "s36", "s37", "s38", "s39", "s40", "s41", "s42", "s43", "s44", "s45", "s46", "s47", "s48", "s49", "s50", "s51", "s52", "s53", "s54", "s55",

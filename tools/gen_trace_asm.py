@@ -41,7 +41,7 @@ def s2(n):
     return "s[%d:%d]" % (n, n + 1)
 
 
-def scan():
+def scan_sorted():
     t = ["v%d" % (64 + i) for i in range(6)]
     tn, tf, span, tc, x, r = "v70", "v71", "v72", "v73", "v74", "v75"
     L = []
@@ -118,6 +118,139 @@ def scan():
           "s_bitcmp1_b32 %s, 31" % RMETA,
           "s_cbranch_scc0 LT_leaf_%=",
           # ---- a branch: its children become the current block; the parent is kept only if it has children left
+          "s_and_b32 %s, %s, 0xff" % (OFF, RMETA),
+          "s_cbranch_scc0 LT_next_%=",
+          "s_cmp_lt_u32 %s, 8" % IDX,
+          "s_cbranch_scc0 LT_nopush_%=",
+          "v_writelane_b32 %s, %s, m0" % (ST_FIRST, FIRST),
+          "v_writelane_b32 %s, %s, m0" % (ST_CUR, REM),
+          "v_writelane_b32 %s, s72, m0" % ST_LO,
+          "v_writelane_b32 %s, s73, m0" % ST_HI,
+          "s_add_u32 m0, m0, 1",
+          "LT_nopush_%=:",
+          "s_mov_b32 %s, %s" % (FIRST, RFIRST),
+          "s_or_b32 %s, %s, 0x100" % (REM, OFF),
+          "s_mov_b64 %s, %s" % (TMASK, ACC),
+          "s_mov_b64 %s, %s" % (MINE, ACC),
+          "s_lshl_b32 %s, %s, 5" % (OFF, RFIRST),
+          "s_add_u32 s68, %s, %s" % (NODES[0], OFF),
+          "s_addc_u32 s69, %s, 0" % NODES[1],
+          "s_branch LT_enter_%="]
+    return L
+
+
+def scan_zero(pattern):
+    """Scan and classification for a wave whose rays share the zero pattern `pattern` of their directions (bit k: component k
+    is exactly zero): rt_node_zero_outside as the quick rejection, rt_node_slab_zero_d as the full classification (rt_math.h).
+    The records are the (lo, hi) variant; the non-zero components may differ in sign from lane to lane."""
+    Z = [k for k in range(3) if (pattern >> k) & 1]
+    NZ = [k for k in range(3) if not (pattern >> k) & 1]
+    d = ["v%d" % (64 + i) for i in range(6)]      # lo - e, hi - e per axis
+    ev = ("v40", "v41", EZ)
+    inv = (IX, IY, IZ)
+    side = "v74"
+    mnmx = [("v70", "v71"), ("v72", "v73")]
+    SQ = T64
+    INALL = "s[98:99]"   # (NR is consumed before the tail needs this)
+    L = ["LT_enter_%=:",
+         "s_ff1_i32_b32 %s, %s" % (IDX, REM),
+         "s_lshl_b32 %s, %s, 5" % (OFF, IDX),
+         "s_waitcnt lgkmcnt(0)",
+         "s_load_dwordx8 s[84:91], %s, %s" % (BLK, OFF),
+         "LT_scan_%=:",
+         "s_bitset0_b32 %s, %s" % (REM, IDX),
+         "s_waitcnt lgkmcnt(0)"]
+    for i in range(6):
+        L.append("v_sub_f32 %s, %s, %s" % (d[i], s(NX + i), ev[i // 2]))
+    L += ["v_mov_b32 %s, %s" % (side, s(NX)),
+          "v_sub_f32 %s, %s, %s" % (side, s(NX + 1), side),
+          "s_mov_b32 %s, %s" % (RFIRST, s(NX + 6)),
+          "s_mov_b32 %s, %s" % (RMETA, s(NX + 7)),
+          "s_ff1_i32_b32 %s, %s" % (IDX, REM),
+          "s_lshl_b32 %s, %s, 5" % (OFF, IDX),
+          "s_load_dwordx8 s[84:91], %s, %s" % (BLK, OFF)]
+    for j, k in enumerate(Z):
+        mn, mx = mnmx[j]
+        L += ["v_min_f32_e64 %s, -%s, %s" % (mn, d[2 * k], d[2 * k + 1]),      # A = e - lo = -(lo - e), B = hi - e
+              "v_max_f32_e64 %s, -%s, %s" % (mx, d[2 * k], d[2 * k + 1]),
+              "v_cmp_gt_f32 vcc, 0, %s" % mn,
+              "v_cmp_gt_f32_e64 %s, %s, %s" % (SQ, mx, side),
+              "s_and_b64 %s, %s, vcc" % (SQ, SQ),
+              ("s_mov_b64 %s, %s" if j == 0 else "s_or_b64 %s, %s, " + NR) % ((NR, SQ) if j == 0 else (NR, SQ))]
+    L += ["s_andn2_b64 %s, %s, %s" % (NR, MINE, NR),        # lanes of the branch whose origin is not outside the child's extent on a zero axis
+          "s_cbranch_scc1 LT_tail_%=",
+          "LT_next_%=:",
+          "s_cmp_lt_u32 %s, 8" % IDX,
+          "s_cbranch_scc1 LT_scan_%=",
+          "LT_pop_%=:",
+          "s_cmp_eq_u32 m0, 0",
+          "s_cbranch_scc1 LT_done_%=",
+          "s_add_u32 m0, m0, -1",
+          "s_nop 1",
+          "v_readlane_b32 %s, %s, m0" % (FIRST, ST_FIRST),
+          "v_readlane_b32 %s, %s, m0" % (REM, ST_CUR),
+          "v_readlane_b32 s72, %s, m0" % ST_LO,
+          "v_readlane_b32 s73, %s, m0" % ST_HI,
+          "s_nop 0",
+          "s_and_b64 %s, %s, %s" % (MINE, TMASK, LIVE),
+          "s_cbranch_scc0 LT_pop_%=",
+          "s_lshl_b32 %s, %s, 5" % (OFF, FIRST),
+          "s_add_u32 s68, %s, %s" % (NODES[0], OFF),
+          "s_addc_u32 s69, %s, 0" % NODES[1],
+          "s_branch LT_enter_%=",
+          "LT_tail_%=:",
+          "s_mov_b64 %s, %s" % (UND, NR)]                       # N = mine & ~outside, kept while NR's registers hold `inside on every zero axis`
+    for j, k in enumerate(Z):
+        mn, mx = mnmx[j]
+        L += ["v_cmp_lt_f32 vcc, 0, %s" % mn,
+              "v_cmp_lt_f32_e64 %s, %s, %s" % (SQ, mx, side),
+              ("s_and_b64 %s, %s, vcc" % (INALL, SQ)) if j == 0 else ("s_and_b64 %s, %s, vcc" % (SQ, SQ))]
+        if j == 1:
+            L.append("s_and_b64 %s, %s, %s" % (INALL, INALL, SQ))
+    # slab arithmetic on the non-zero axes: (plane - e) * inv, ordered by min / max
+    n = ["v75", "v77"]
+    f = ["v76", "v78"]
+    for j, k in enumerate(NZ):
+        L += ["v_mul_f32 v32, %s, %s" % (d[2 * k], inv[k]),
+              "v_mul_f32 v33, %s, %s" % (d[2 * k + 1], inv[k]),
+              "v_min_f32 %s, v32, v33" % n[j],
+              "v_max_f32 %s, v32, v33" % f[j]]
+    two = len(NZ) == 2
+    tN, tF, tN2, tF2, M, span, tc, x, a, r = "v34", "v35", "v36", "v37", "v38", "v39", "v32", "v33", "v79", "v70"
+    if two:
+        L += ["v_max_f32 %s, %s, %s" % (tN, n[0], n[1]), "v_min_f32 %s, %s, %s" % (tN2, n[0], n[1]),
+              "v_min_f32 %s, %s, %s" % (tF, f[0], f[1]), "v_max_f32 %s, %s, %s" % (tF2, f[0], f[1]),
+              "v_max_f32_e64 %s, %s, -%s" % (M, tF2, tN2)]
+    else:
+        tN, tF = n[0], f[0]
+        L += ["v_max_f32_e64 %s, %s, -%s" % (M, f[0], n[0])]
+    L += ["v_add_f32 %s, %s, %s" % (M, M, T),
+          "v_mul_f32 %s, 0x37000000, %s" % (M, M),              # E
+          "v_sub_f32 %s, %s, %s" % (span, tF, tN),
+          "v_cmp_lt_f32 vcc, 0, %s" % tN,
+          "v_cndmask_b32 %s, %s, %s, vcc" % (tc, tF, tN),
+          "v_sub_f32 %s, %s, %s" % (x, T, tc),
+          "v_min3_f32 %s, %s, %s, %s" % (r, span, tF, x)]
+    if two:
+        L += ["v_sub_f32 v71, %s, %s" % (tN, tN2),
+              "v_sub_f32 v72, %s, %s" % (tF2, tF),
+              "v_cndmask_b32 v71, v72, v71, vcc",
+              "v_min3_f32 %s, %s, %s, v71" % (a, x, span)]
+    else:
+        L += ["v_min_f32 %s, %s, %s" % (a, x, span)]
+    L += ["v_min_f32 %s, %s, %s" % (a, a, tc),
+          "v_cmp_gt_f32_e64 %s, %s, %s" % (ACC, a, M),
+          "v_cmp_lt_f32_e64 %s, %s, -%s" % (SQ, r, M),            # rejected by the slab arithmetic
+          "s_and_b64 %s, %s, %s" % (ACC, ACC, INALL),
+          "s_andn2_b64 %s, %s, %s" % (UND, UND, SQ),               # N & ~rejected
+          "s_and_b64 %s, %s, %s" % (ACC, ACC, UND),
+          "s_andn2_b64 %s, %s, %s" % (UND, UND, ACC),
+          "s_cbranch_scc1 LT_exit_exact_%=",
+          "LT_after_exact_%=:",
+          "s_cmp_eq_u64 %s, 0" % ACC,
+          "s_cbranch_scc1 LT_next_%=",
+          "s_bitcmp1_b32 %s, 31" % RMETA,
+          "s_cbranch_scc0 LT_leaf_%=",
           "s_and_b32 %s, %s, 0xff" % (OFF, RMETA),
           "s_cbranch_scc0 LT_next_%=",
           "s_cmp_lt_u32 %s, 8" % IDX,
@@ -255,13 +388,13 @@ def leaf():
     return L
 
 
-def main():
+def block(pattern):
     L = ["s_waitcnt lgkmcnt(0)",
          "s_cmp_eq_u32 %s, 1" % RES,
          "s_cbranch_scc1 LT_resume_exact_%=",
          "s_cmp_eq_u32 %s, 2" % RES,
          "s_cbranch_scc1 LT_resume_finish_%="]
-    L += scan()
+    L += scan_sorted() if pattern == 0 else scan_zero(pattern)
     L += leaf()
     L += [# ---- re-entries: the record of the next sibling is requested again (its registers were not kept outside)
           "LT_resume_exact_%=:",
@@ -282,14 +415,29 @@ def main():
           "s_mov_b32 %s, 0" % RES,
           "LT_out_%=:",
           "s_waitcnt lgkmcnt(0)"]
-    # In the second half the record sits at TP (TP was moved), so the exit to the quotients must not skip one more: both
-    # halves add 0x40 ("the record behind this one") - correct for either, because TP names the record under test in both.
+    return L
+
+
+def main():
+    # (in both halves of the leaf loop TP names the record under test, so the exit to the quotients adds 0x40 in either)
     out = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "raytracer_amd", "csrc", "rt_trace_asm.inc")
     with open(out, "w") as f:
         f.write("// Generated by tools/gen_trace_asm.py - do not edit.  Register map and operands: rt_kernel_wave.hip (trace_wave).\n")
-        for line in L:
-            f.write('"%s\\n"\n' % line)
-    print("wrote", os.path.normpath(out), len(L), "lines")
+        f.write("// RT_TRACE_ASM_0: rays that agree on their direction signs; RT_TRACE_ASM_1 .. _6: rays that share a zero pattern (bit k: component k is zero).\n")
+        # ONE assembly statement with the seven copies behind a dispatch on the pattern (s18): several statements in a
+        # switch would have the compiler merge their scalar outputs through values it no longer knows to be wave-uniform
+        L = []
+        for pattern in range(1, 7):
+            L += ["s_cmp_eq_u32 s18, %d" % pattern, "s_cbranch_scc1 LT%d_begin_%%=" % pattern]
+        for pattern in range(7):
+            B = ["LT%d_begin_%%=:" % pattern] + block(pattern) + ["s_branch LT_end_all_%="]
+            L += [line.replace("LT_", "LT%d_" % pattern) if "LT_end_all" not in line else line for line in B]
+            print("pattern", pattern, len(B), "lines")
+        L += ["LT_end_all_%=:"]
+        f.write("#define RT_TRACE_ASM \\\n")
+        f.write(" \\\n".join('"%s\\n"' % line for line in L))
+        f.write("\n")
+    print("wrote", os.path.normpath(out))
 
 
 if __name__ == "__main__":
