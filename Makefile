@@ -17,7 +17,7 @@ all: $(LIB) $(RUN) oracle
 $(CSRC)/rt_host.o: $(CSRC)/rt_host.cpp $(CSRC)/rt_internal.h include/rt_amd.h
 	$(CXX) $(HOSTFLAGS) -c $< -o $@
 
-HIPOBJS := $(CSRC)/rt_device.o $(CSRC)/rt_kernel_lane.o $(CSRC)/rt_kernel_wave.o $(CSRC)/rt_sort.o $(CSRC)/rt_gather.o
+HIPOBJS := $(CSRC)/rt_device.o $(CSRC)/rt_kernel_lane.o $(CSRC)/rt_kernel_wave.o $(CSRC)/rt_queue.o $(CSRC)/rt_gather.o
 
 $(CSRC)/%.o: $(CSRC)/%.hip $(CSRC)/rt_kernels.h $(CSRC)/rt_internal.h $(CSRC)/rt_math.h $(CSRC)/rt_trace_asm.inc include/rt_amd.h
 	$(HIPCC) $(HIPFLAGS) -c $< -o $@

@@ -82,9 +82,8 @@ struct Arena {
 
 // Offsets of the queue-mode buffers inside an arena (all 256-byte aligned).
 struct WavefrontLayout {
-  size_t queue[2], keys[2], vals[2], ray_keys[2], ray_index[2], ray_sort_temp, sort_temp, counts, total;
-  size_t ray_sort_temp_bytes, sort_temp_bytes;
-  uint32_t queue_cap, term_cap;
+  size_t state, queue[2], keys, order, bins, sums, block_pixel, terms, terms_bytes, total;
+  uint32_t queue_cap, block_cap, slots;
 };
 
 size_t carve(size_t& cursor, size_t bytes) {
@@ -93,38 +92,42 @@ size_t carve(size_t& cursor, size_t bytes) {
   return at;
 }
 
-int wavefront_layout(uint32_t queue_cap, uint32_t term_cap, hipStream_t stream, WavefrontLayout* L) {
+void wavefront_layout(uint32_t queue_cap, uint32_t block_cap, uint32_t slots, WavefrontLayout* L) {
   size_t c = RT_COUNTER_BYTES;
-  L->queue_cap = queue_cap; L->term_cap = term_cap;
-  L->counts = carve(c, 4 * sizeof(uint32_t));
+  L->queue_cap = queue_cap; L->block_cap = block_cap; L->slots = slots;
+  L->state = carve(c, sizeof(RtQState));
   for (int k = 0; k < 2; k++) L->queue[k] = carve(c, (size_t)queue_cap * sizeof(RtQRay));
-  for (int k = 0; k < 2; k++) L->ray_keys[k] = carve(c, (size_t)queue_cap * sizeof(uint32_t));
-  for (int k = 0; k < 2; k++) L->ray_index[k] = carve(c, (size_t)queue_cap * sizeof(uint32_t));
-  for (int k = 0; k < 2; k++) L->keys[k] = carve(c, (size_t)term_cap * sizeof(unsigned long long));
-  for (int k = 0; k < 2; k++) L->vals[k] = carve(c, (size_t)term_cap * sizeof(RtTermRGB));
-  // sizes of the sorts' work areas (a query: nothing is launched, nothing allocated)
-  size_t rb = 0, tb = 0;
-  HIP_TRY(rt_sort_u32(nullptr, &rb, nullptr, nullptr, nullptr, nullptr, queue_cap, 30u, stream));
-  HIP_TRY(rt_sort_terms(nullptr, &tb, nullptr, nullptr, nullptr, nullptr, term_cap, 64u, stream));
-  L->ray_sort_temp_bytes = rb; L->sort_temp_bytes = tb;
-  L->ray_sort_temp = carve(c, rb ? rb : 16);
-  L->sort_temp = carve(c, tb ? tb : 16);
+  L->keys = carve(c, (size_t)queue_cap * sizeof(uint32_t));
+  L->order = carve(c, (size_t)queue_cap * sizeof(uint32_t));
+  L->bins = carve(c, (size_t)RT_QBINS * sizeof(uint32_t));
+  L->sums = carve(c, (size_t)RT_QBIN_BLOCKS * sizeof(uint32_t));
+  L->block_pixel = carve(c, (size_t)block_cap * sizeof(uint32_t));
+  L->terms_bytes = (size_t)slots * block_cap * sizeof(RtTermRGB);
+  L->terms = carve(c, L->terms_bytes);
   L->total = c;
-  return RT_OK;
 }
+
+// Which part of an arena currently is a cleared term pool, and the tag of the last frame rendered into it.  A slot
+// counts when its tag is the frame's; the tags of one pool never repeat, so nothing is cleared between frames - only when
+// the pool moves or changes size (other data may have lain there) or the tag would wrap.
+struct TermPool { size_t at = 0, bytes = 0; uint32_t tag = 0; };
 
 // One frame in flight: its scratch arena, and the buffers of the host-memory entry point (device frame + pinned staging),
 // kept from call to call.
 struct RenderCtx {
   Arena arena;
   WavefrontLayout wf_layout; bool wf_laid_out = false;
+  TermPool own_pool; TermPool* pool = &own_pool;   // (the fixed arena's lives with the arena, not with the context)
   uint8_t* d_rgb = nullptr; int32_t* d_ids = nullptr; float* d_t = nullptr; size_t frame_px = 0;
   void* pinned = nullptr; size_t pinned_bytes = 0;
   hipStream_t host_stream = nullptr;
   void* landing = nullptr;   // page-locked host words for read-backs (borrowed, never freed here); nullptr: pageable memory
+  RenderCtx() = default;
+  RenderCtx(const RenderCtx&) = delete;
+  RenderCtx& operator=(const RenderCtx&) = delete;
   void release() {
     if (!arena.fixed) (void)hipFree(arena.base);
-    arena = Arena();
+    arena = Arena(); own_pool = TermPool(); wf_laid_out = false;
     (void)hipFree(d_rgb); (void)hipFree(d_ids); (void)hipFree(d_t); d_rgb = nullptr; d_ids = nullptr; d_t = nullptr; frame_px = 0;
     if (pinned) (void)hipHostFree(pinned);
     pinned = nullptr; pinned_bytes = 0;
@@ -157,7 +160,8 @@ static __device__ __align__(256) unsigned char scratch[RT_STATIC_SCRATCH_BYTES];
 
 struct StaticScratch {
   unsigned char* ptr = nullptr;   // device address of `scratch` on this device
-  void* landing = nullptr;        // page-locked host words the counters and queue fills are copied into
+  void* landing = nullptr;        // page-locked host words the counters and the queue state are copied into
+  TermPool pool;                  // (the array starts out zeroed, like a pool that was just cleared nowhere: see TermPool)
   bool ready = false;
 };
 StaticScratch g_static[RT_STATIC_MAX_DEVICES];
@@ -245,26 +249,37 @@ extern "C" int rt_dscene_fork(const rt_dscene* d, rt_dscene** out) {
 namespace {
 
 // Bounce rays generation by generation (see RtQueues).  Eligible when the reference's 10-entry stack can never overflow,
-// so that leaving the stack out changes nothing: a ray at depth k <= D-1 finds at most k (p-1) older entries and pushes
-// p more (D = ray depth limit, p = most pushes of one hit).
+// so that leaving the stack out changes nothing - a ray at depth k <= D-1 finds at most k (p-1) older entries and pushes
+// p more (D = ray depth limit, p = most pushes of one hit) - and when a pixel's ray tree has few enough nodes for a
+// block of term slots.
 // Is the scene rendered from queues, and is the arena ready for it?  *eligible = false: the stacked way (ineligible scene
 // or frame).  Called before anything of the frame is enqueued, because it may replace the arena.
+constexpr unsigned long long RT_TERM_POOL_MAX_BYTES = 8ull << 30;   // of a context's arena; a frame that needs more blocks falls back
+
+uint32_t tree_slots(int D, int p) {   // 1 + p + ... + p^D, saturating
+  unsigned long long n = 0, level = 1;
+  for (int k = 0; k <= D; k++) { n += level; level *= (unsigned long long)p; if (n > 0xffffffffull) return 0xffffffffu; }
+  return (uint32_t)n;
+}
+
 int prepare_wavefront(const SceneArrays& S, RenderCtx& ctx, const RowMap& rows, hipStream_t stream, bool* eligible) {
   *eligible = false;
   const int D = S.view.cam.max_depth, p = S.max_pushes_per_hit;
   const unsigned long long n_out = (unsigned long long)S.view.cam.width * (rows.compact ? rows.n_local : S.view.cam.height);
-  const int path_bits = 4 * std::max(D, 1);
-  // (a queued ray names its pixel by a 32-bit position in the output buffer)
-  if (p < 1 || p > RT_PATH_MAX_PUSHES || D > 9 || (D - 1) * (p - 1) + p > RT_RAY_STACK || n_out >= (1ull << (64 - path_bits)) || n_out > 0xffffffffull) return RT_OK;
+  // (a block names its pixel by a 32-bit position in the output buffer)
+  if (p < 1 || D < 1 || (D - 1) * (p - 1) + p > RT_RAY_STACK || n_out > 0xffffffffull) return RT_OK;
+  const uint32_t slots = tree_slots(D, p);
+  if (slots > RT_TERM_SLOTS_MAX) return RT_OK;
   const unsigned long long n_px = (unsigned long long)S.view.cam.width * rows.n_local;
   // a fixed arena is cut to what the call needs; one that may grow keeps a floor so that small frames do not make it grow step by step
   const unsigned long long floor_n = ctx.arena.fixed ? 64ull : (1ull << 16);
-  const unsigned long long want_q = std::max<unsigned long long>(floor_n, 2 * n_px), want_t = std::max<unsigned long long>(floor_n, 3 * n_px);
-  if (want_q > 0xffffffffull / 2 || want_t > 0xffffffffull / 2) return RT_OK;
-  if (!ctx.wf_laid_out || ctx.wf_layout.queue_cap < want_q || ctx.wf_layout.term_cap < want_t || ctx.arena.fixed) {
+  const unsigned long long want_q = std::max<unsigned long long>(floor_n, 2 * n_px);
+  unsigned long long want_b = std::max<unsigned long long>(floor_n, n_px);
+  if (!ctx.arena.fixed) want_b = std::min<unsigned long long>(want_b, RT_TERM_POOL_MAX_BYTES / ((unsigned long long)slots * sizeof(RtTermRGB)));
+  if (want_q > 0xffffffffull / 2 || want_b > 0xffffffffull / 2) return RT_OK;
+  if (!ctx.wf_laid_out || ctx.wf_layout.queue_cap < want_q || ctx.wf_layout.block_cap < want_b || ctx.wf_layout.slots != slots || ctx.arena.fixed) {
     WavefrontLayout L;
-    int rc = wavefront_layout((uint32_t)want_q, (uint32_t)want_t, stream, &L);
-    if (rc != RT_OK) return rc;
+    wavefront_layout((uint32_t)want_q, (uint32_t)want_b, slots, &L);
     if (ctx.arena.bytes < L.total) {
       if (ctx.arena.fixed) {
         rt_set_error("the bounce-ray queues of " + std::to_string(n_px) + " pixels need " + std::to_string(L.total) + " bytes of scratch and the static array holds " +
@@ -272,7 +287,9 @@ int prepare_wavefront(const SceneArrays& S, RenderCtx& ctx, const RowMap& rows, 
         return RT_ERR_LIMIT;
       }
       HIP_TRY(hipStreamSynchronize(stream));   // nothing may still be using the arena that is about to be replaced
+      int rc;
       if ((rc = arena_reserve(ctx.arena, L.total, "bounce-ray queues")) != RT_OK) return rc;
+      *ctx.pool = TermPool();
     }
     ctx.wf_layout = L; ctx.wf_laid_out = true;
   }
@@ -280,66 +297,64 @@ int prepare_wavefront(const SceneArrays& S, RenderCtx& ctx, const RowMap& rows, 
   return RT_OK;
 }
 
-// *done = false: a queue would have overflowed; the caller renders the stacked way instead.
+// The order in which the reference's stack works off a pixel's rays: a ray, then the rays it pushed, the last one first,
+// each with everything below it (ray.cuh:22-33).
+void slot_order(uint32_t slot, int depth, int D, int p, RtSlotOrder* o) {
+  o->slot[o->n++] = (uint8_t)slot;
+  if (depth < D) for (int k = p - 1; k >= 0; k--) slot_order(slot * (uint32_t)p + 1u + (uint32_t)k, depth + 1, D, p, o);
+}
+
+// *done = false: a queue or the block pool was too small; the caller renders the stacked way instead.
+// Everything is enqueued back to back - how many rays a generation holds stays on the device; the one read-back at the
+// end tells whether something overflowed.
 int render_wavefront(const SceneArrays& S, RenderCtx& ctx, const RowMap& rows, bool count, uint8_t* d_rgb, int32_t* d_ids, float* d_t, bool tally,
                      hipStream_t stream, bool* done) {
   *done = false;
-  const int D = S.view.cam.max_depth;
-  const unsigned long long n_out = (unsigned long long)S.view.cam.width * (rows.compact ? rows.n_local : S.view.cam.height);
-  const int path_bits = 4 * std::max(D, 1);
+  const int D = S.view.cam.max_depth, p = S.max_pushes_per_hit;
   const WavefrontLayout& L = ctx.wf_layout;
   unsigned char* const base = ctx.arena.base;
   unsigned long long* const counters = (unsigned long long*)base;
-  uint32_t* const counts = (uint32_t*)(base + L.counts);
+  RtQState* const state = (RtQState*)(base + L.state);
   RtQRay* const queue[2] = {(RtQRay*)(base + L.queue[0]), (RtQRay*)(base + L.queue[1])};
-  unsigned long long* const keys[2] = {(unsigned long long*)(base + L.keys[0]), (unsigned long long*)(base + L.keys[1])};
-  RtTermRGB* const vals[2] = {(RtTermRGB*)(base + L.vals[0]), (RtTermRGB*)(base + L.vals[1])};
-  uint32_t* const ray_keys[2] = {(uint32_t*)(base + L.ray_keys[0]), (uint32_t*)(base + L.ray_keys[1])};
-  uint32_t* const ray_index[2] = {(uint32_t*)(base + L.ray_index[0]), (uint32_t*)(base + L.ray_index[1])};
-  HIP_TRY(hipMemsetAsync(counts, 0, 4 * sizeof(uint32_t), stream));
+  TermPool& pool = *ctx.pool;
+  if (pool.at != L.terms || pool.bytes != L.terms_bytes || pool.tag == 0xffffffffu) {
+    HIP_TRY(hipMemsetAsync(base + L.terms, 0, L.terms_bytes, stream));
+    pool.at = L.terms; pool.bytes = L.terms_bytes; pool.tag = 0u;
+  }
+  pool.tag++;
+  HIP_TRY(hipMemsetAsync(state, 0, sizeof(RtQState), stream));
   RtQueues q;
-  q.in = nullptr; q.order = nullptr; q.n_in = 0; q.out = queue[0]; q.out_count = counts + 0; q.out_cap = L.queue_cap;
-  q.term_keys = keys[0]; q.term_vals = vals[0]; q.term_count = counts + 2; q.term_cap = L.term_cap; q.enabled = 1; q.path_bits = path_bits; q.rays_per_wave = 64;
+  memset(&q, 0, sizeof q);
+  q.in = nullptr; q.out = queue[0]; q.order = nullptr; q.state = state;
+  q.terms = (RtTermRGB*)(base + L.terms); q.block_pixel = (uint32_t*)(base + L.block_pixel);
+  q.in_index = 1u; q.out_index = 0u; q.queue_cap = L.queue_cap; q.block_cap = L.block_cap; q.pushes = (uint32_t)p; q.tag = pool.tag; q.enabled = 1;
   rt_launch_wave_kernel(S.view, rows, true, count, d_rgb, d_ids, d_t, counters, tally, q, stream);
   HIP_TRY(hipGetLastError());
-  uint32_t h_pageable[4];
-  // (a context with page-locked landing words keeps the queue fills behind the counters' place there)
-  uint32_t* const h = ctx.landing ? (uint32_t*)((unsigned char*)ctx.landing + RT_COUNTER_BYTES) : h_pageable;
-  int cur = 0;
-  const float root_lo = -RT_INF / 4, root_side = RT_INF / 2;   // the octree's root cube (main.cu:25-31)
-  for (int gen = 1; gen <= D + 1; gen++) {
-    HIP_TRY(hipMemcpyAsync(h, counts, 4 * sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
-    HIP_TRY(hipStreamSynchronize(stream));
-    if (h[cur] > L.queue_cap || h[2] > L.term_cap) return RT_OK;   // would not fit: render the stacked way
-    if (h[cur] == 0) break;
-    HIP_TRY(hipMemsetAsync(counts + (cur ^ 1), 0, sizeof(uint32_t), stream));
-    q.in = queue[cur]; q.n_in = h[cur]; q.out = queue[cur ^ 1]; q.out_count = counts + (cur ^ 1);
-    q.order = nullptr;
-    q.rays_per_wave = h[cur] < 131072u ? 16 : 64;   // a short queue: shorter walks in four times as many waves (measured break-even)
-    static const bool sort_rays = !(getenv("RT_AMD_SORT_RAYS") && atoi(getenv("RT_AMD_SORT_RAYS")) == 0);   // measurements
-    if (sort_rays && S.view.has_oct && h[cur] >= 4096) {   // the queue is put in an order that keeps similar rays together
-      // measured on the glass bunny: with a million rays a generation (4K) grouping by octant first wins (9.0 -> 7.0 ms, origin
-      // first 8.2); with a few hundred thousand (720p, 1080p) grouping by origin first does (4.1 -> 3.7 ms, 4.4 -> 3.9 ms)
-      rt_launch_ray_keys(queue[cur], h[cur], root_lo, root_side, h[cur] >= 600000u, ray_keys[0], ray_index[0], stream);
-      size_t rb = L.ray_sort_temp_bytes;
-      HIP_TRY(rt_sort_u32(base + L.ray_sort_temp, &rb, ray_keys[0], ray_keys[1], ray_index[0], ray_index[1], h[cur], 30u, stream));
-      q.order = ray_index[1];
+  static const bool sort_rays = !(getenv("RT_AMD_SORT_RAYS") && atoi(getenv("RT_AMD_SORT_RAYS")) == 0);   // measurements
+  uint32_t cur = 0u;
+  for (int gen = 1; gen <= D; gen++) {   // rays of depth `gen` (camera.cu:104-112 works them off one by one)
+    rt_launch_queue_advance(state, cur ^ 1u, stream);
+    q.in = queue[cur]; q.in_index = cur; q.out = queue[cur ^ 1u]; q.out_index = cur ^ 1u; q.order = nullptr;
+    if (sort_rays && S.view.has_oct) {   // the queue is put in an order that keeps similar rays together
+      uint32_t* const order = (uint32_t*)(base + L.order);
+      rt_launch_ray_order(queue[cur], state, cur, L.queue_cap, (uint32_t*)(base + L.keys), (uint32_t*)(base + L.bins),
+                          (uint32_t*)(base + L.sums), order, stream);
+      q.order = order;
     }
     rt_launch_wave_kernel(S.view, rows, true, count, nullptr, nullptr, nullptr, counters, tally, q, stream);
     HIP_TRY(hipGetLastError());
-    cur ^= 1;
+    cur ^= 1u;
   }
-  HIP_TRY(hipMemcpyAsync(h, counts, 4 * sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
+  RtSlotOrder order; order.n = 0u;
+  slot_order(0u, 0, D, p, &order);
+  rt_launch_resolve_blocks(q, order, d_rgb, stream);
+  HIP_TRY(hipGetLastError());
+  RtQState h_pageable;
+  // (a context with page-locked landing words keeps the queue state behind the counters' place there)
+  RtQState* const h = ctx.landing ? (RtQState*)((unsigned char*)ctx.landing + RT_COUNTER_BYTES) : &h_pageable;
+  HIP_TRY(hipMemcpyAsync(h, state, sizeof(RtQState), hipMemcpyDeviceToHost, stream));
   HIP_TRY(hipStreamSynchronize(stream));
-  if (h[2] > L.term_cap || h[cur] != 0) return RT_OK;
-  if (h[2] > 0) {
-    unsigned end_bit = (unsigned)path_bits;   // only the bits that can be set are sorted on
-    while (end_bit < 64 && (n_out >> (end_bit - path_bits)) != 0) end_bit++;
-    size_t bytes = L.sort_temp_bytes;
-    HIP_TRY(rt_sort_terms(base + L.sort_temp, &bytes, keys[0], keys[1], vals[0], vals[1], h[2], end_bit, stream));
-    rt_launch_resolve_terms(keys[1], vals[1], h[2], path_bits, d_rgb, stream);
-    HIP_TRY(hipGetLastError());
-  }
+  if (h->overflow || h->n_blocks > L.block_cap || h->count[0] > L.queue_cap || h->count[1] > L.queue_cap) return RT_OK;
   *done = true;
   return RT_OK;
 }
@@ -457,7 +472,7 @@ extern "C" int rt_render_rows_static(rt_dscene* d, int row_begin, int row_end, u
   // a context on the stack around this GPU's copy of the array: nothing in it is owned, nothing is freed
   RenderCtx ctx;
   ctx.arena.base = g_static[device].ptr; ctx.arena.bytes = RT_STATIC_SCRATCH_BYTES; ctx.arena.fixed = true;
-  ctx.landing = g_static[device].landing;
+  ctx.landing = g_static[device].landing; ctx.pool = &g_static[device].pool;
   return launch_render(*d->scene, ctx, plain_rows(row_begin, row_end), d_rgb, d_ids, d_t, (hipStream_t)stream, flags, stats);
 }
 

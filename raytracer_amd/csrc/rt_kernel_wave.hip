@@ -890,44 +890,37 @@ __global__ __launch_bounds__(RT_WBLOCK, BOUNCE ? RT_WAVES_PER_SIMD_BOUNCE : (DEN
   sh.att = {1.f, 1.f, 1.f}; sh.level0 = c.scene_refr; sh.nlevel = 0; sh.depth = 0;
   BounceRay rstack[BOUNCE ? RT_RAY_STACK : 1];
   int rsp = 0;
-  // queue mode: where the lane's ray sits in its pixel's ray tree, how many rays it has pushed, whether the pixel is
-  // finished by the term list instead of by this lane
-  uint32_t q_pixel = 0u; unsigned long long q_path = 0ull; int q_pushes = 0; bool q_pending = false;
-  if (queued) {
-    const RtQueues& wf = A.wf;
-    const uint32_t per_wave = (uint32_t)wf.rays_per_wave;
-    const uint32_t gid = (blockIdx.x * (RT_WBLOCK / 64) + (tid >> 6)) * per_wave + lane;
-    phase = PH_DONE; tr_e = {0.f, 0.f, 0.f}; tr_d = {0.f, 0.f, 1.f};
-    if ((uint32_t)lane < per_wave && gid < wf.n_in) {
-      const RtQRay& q = wf.in[wf.order ? wf.order[gid] : gid];
-      tr_e = ld3(q.e); tr_d = ld3(q.d); sh.att = ld3(q.att);
-      sh.level0 = q.level[0]; sh.level1 = q.level[1]; sh.level2 = q.level[2]; sh.nlevel = q.nlevel; sh.depth = q.depth;
-      q_pixel = q.pixel; q_path = q.path;
-      phase = PH_CLOSEST; tl.rays++;
-    }
-    sh.view = tr_d;
-  }
+  // queue mode: the term block of the lane's pixel, the ray's node in the pixel's ray tree, how many rays it has pushed
+  uint32_t q_block = 0u, q_slot = 0u; int q_pushes = 0;
   // A ray pushed by the hit being shaded (ray.cuh:22-27): onto the lane's stack, or into the queue of the next generation.
   auto push_ray = [&](const RtVec3& eye, const RtVec3& dir, const RtVec3& att, int nlevel) {
     if (BOUNCE && wavefront) {
       const RtQueues wf = LATE_STRUCT(wf);
-      if (!queued && q_pushes == 0) { const Pixel px = pixel_of(tid); q_pixel = (uint32_t)((size_t)px.orow * LATE(cam).width + px.col); }
-      // one slot per pushing lane: the lanes active here count themselves and the first of them reserves the run
+      // the lanes active here count themselves; the first of them reserves a run for all (one atomic per wave)
       const uint64_t m = __builtin_amdgcn_ballot_w64(true);
       const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+      if (!queued && q_pushes == 0) {   // a primary ray's first push: its pixel gets a block of term slots
+        const Pixel px = pixel_of(tid);
+        const uint64_t mb = __builtin_amdgcn_ballot_w64(true);
+        const uint32_t rb = __builtin_amdgcn_mbcnt_hi((uint32_t)(mb >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mb, 0u));
+        uint32_t bb = 0u;
+        if (rb == 0u) bb = atomicAdd(&wf.state->n_blocks, (uint32_t)__builtin_popcountll(mb));
+        bb = __builtin_amdgcn_readfirstlane(bb);
+        q_block = bb + rb; q_slot = 0u;
+        if (q_block < wf.block_cap) wf.block_pixel[q_block] = (uint32_t)((size_t)px.orow * LATE(cam).width + px.col);
+        else wf.state->overflow = 1u;   // (the host then renders the frame the other way)
+      }
       uint32_t base = 0u;
-      if (rank == 0u) base = atomicAdd(wf.out_count, (uint32_t)__builtin_popcountll(m));
+      if (rank == 0u) base = atomicAdd(&wf.state->count[wf.out_index], (uint32_t)__builtin_popcountll(m));
       base = __builtin_amdgcn_readfirstlane(base);
-      const uint32_t slot = base + rank;
-      const int depth = sh.depth + 1;
-      if (slot < wf.out_cap) {   // (an overflow shows in the count; the host then renders the frame the other way)
-        RtQRay& q = wf.out[slot];
+      const uint32_t at = base + rank;
+      if (at < wf.queue_cap) {
+        RtQRay& q = wf.out[at];
         q.e[0] = eye.x; q.e[1] = eye.y; q.e[2] = eye.z; q.d[0] = dir.x; q.d[1] = dir.y; q.d[2] = dir.z;
         q.att[0] = att.x; q.att[1] = att.y; q.att[2] = att.z;
-        q.level[0] = sh.level0; q.level[1] = sh.level1; q.level[2] = sh.level2; q.nlevel = nlevel; q.depth = depth;
-        q.pixel = q_pixel; q.pad = 0u;
-        q.path = q_path | ((unsigned long long)(RT_PATH_MAX_PUSHES - q_pushes) << (wf.path_bits - 4 * depth));
-      }
+        q.level[0] = sh.level0; q.level[1] = sh.level1; q.level[2] = sh.level2; q.nlevel = nlevel; q.depth = sh.depth + 1;
+        q.block = q_block; q.slot = q_slot * wf.pushes + 1u + (uint32_t)q_pushes;
+      } else wf.state->overflow = 1u;
       q_pushes++;
     } else if (BOUNCE) {
       if (rsp < RT_RAY_STACK) {
@@ -939,6 +932,30 @@ __global__ __launch_bounds__(RT_WBLOCK, BOUNCE ? RT_WAVES_PER_SIMD_BOUNCE : (DEN
     }
   };
 
+  // A launch that renders a queue: one chunk of the queue per wave.  How long the queue is, is only known on the device; the
+  // launch has a wave for every chunk of a full queue, and a wave whose chunk lies beyond the queue's end leaves at once.
+  // (Waves that stay and take chunk after chunk by ticket were measured too: the glass bunny at 4K took 7.6 ms that way
+  // against 5.3 ms, at 1920x1080 3.8 against 3.2 ms.)
+  if (queued) {
+    const RtQueues wf = LATE_STRUCT(wf);
+    uint32_t n_in = wf.state->count[wf.in_index];
+    n_in = n_in < wf.queue_cap ? n_in : wf.queue_cap;
+    n_in = __builtin_amdgcn_readfirstlane(n_in);
+    // a short queue: shorter walks in four times as many waves (measured break-even)
+    const uint32_t per_wave = n_in < RT_QUEUE_SMALL ? 16u : 64u;
+    const uint32_t chunk = blockIdx.x * (RT_WBLOCK / 64) + (uint32_t)(tid >> 6);
+    if ((unsigned long long)chunk * per_wave >= n_in) return;
+    const uint32_t gid = chunk * per_wave + lane;
+    phase = PH_DONE; tr_e = {0.f, 0.f, 0.f}; tr_d = {0.f, 0.f, 1.f};
+    if ((uint32_t)lane < per_wave && gid < n_in) {
+      const RtQRay& q = wf.in[(wf.order && n_in >= RT_QUEUE_SORT_MIN) ? wf.order[gid] : gid];
+      tr_e = ld3(q.e); tr_d = ld3(q.d); sh.att = ld3(q.att);
+      sh.level0 = q.level[0]; sh.level1 = q.level[1]; sh.level2 = q.level[2]; sh.nlevel = q.nlevel; sh.depth = q.depth;
+      q_block = q.block; q_slot = q.slot;
+      phase = PH_CLOSEST; tl.rays++;
+    }
+    sh.view = tr_d;
+  }
   while (__builtin_amdgcn_ballot_w64(phase != PH_DONE)) {
     // ---- trace the pending rays of the wave ---------------------------------------------------------
     Hit h = {RT_INF, -1, 0.f, 0.f};
@@ -998,20 +1015,10 @@ __global__ __launch_bounds__(RT_WBLOCK, BOUNCE ? RT_WAVES_PER_SIMD_BOUNCE : (DEN
       while (phase == PH_SHADE) {
         if (sh.mi >= sh.mcount) {   // every material of the hit handled: camera.cu:110-111, then next ray of the pixel
           if (BOUNCE && wavefront && (queued || q_pushes > 0)) {
-            // the ray's contribution goes to the term list; the pixel is summed up from there, in the reference's order
+            // the ray's contribution goes to its slot of the pixel's block; the pixel is summed up from there, in the reference's order
             const RtQueues wf = LATE_STRUCT(wf);
-            if (!queued && q_pushes == 0) { const Pixel px = pixel_of(tid); q_pixel = (uint32_t)((size_t)px.orow * LATE(cam).width + px.col); }
-            const uint64_t m = __builtin_amdgcn_ballot_w64(true);
-            const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
-            uint32_t base = 0u;
-            if (rank == 0u) base = atomicAdd(wf.term_count, (uint32_t)__builtin_popcountll(m));
-            base = __builtin_amdgcn_readfirstlane(base);
-            const uint32_t slot = base + rank;
-            if (slot < wf.term_cap) {
-              wf.term_keys[slot] = ((unsigned long long)q_pixel << wf.path_bits) | q_path;
-              wf.term_vals[slot] = RtTermRGB{sh.att.x * sh.colr.x, sh.att.y * sh.colr.y, sh.att.z * sh.colr.z, 0.f};
-            }
-            q_pending = true;
+            if (q_block < wf.block_cap)
+              wf.terms[(size_t)q_slot * wf.block_cap + q_block] = RtTermRGB{sh.att.x * sh.colr.x, sh.att.y * sh.colr.y, sh.att.z * sh.colr.z, wf.tag};
             phase = PH_DONE;
             break;
           }
@@ -1154,7 +1161,6 @@ __global__ __launch_bounds__(RT_WBLOCK, BOUNCE ? RT_WAVES_PER_SIMD_BOUNCE : (DEN
       rgb[p] = q[0]; rgb[p + 1] = q[1]; rgb[p + 2] = q[2];
     }
   }
-  (void)q_pending;
 #ifdef RT_WAVE_TIMES
   float* const ts = LATE(ts);
   if (ts && !queued && lane == 0) {
@@ -1185,9 +1191,11 @@ void rt_launch_wave_kernel(const RtDeviceView& V, const RowMap& rows, bool bounc
                            float* ts, unsigned long long* counters, bool tally, const RtQueues& wf, hipStream_t stream) {
   const int tw = rows.small ? RT_WTILE_W / 2 : RT_WTILE_W, th = rows.small ? RT_WTILE_H / 2 : RT_WTILE_H;
   dim3 grid((V.cam.width + tw - 1) / tw, (rows.n_local + th - 1) / th), block(RT_WBLOCK);
-  if (wf.in) {   // one queued ray per lane (or per lane of the first quarter of each wave)
-    const uint32_t per_block = (RT_WBLOCK / 64) * (uint32_t)wf.rays_per_wave;
-    grid = dim3((wf.n_in + per_block - 1) / per_block, 1); bounce = true;
+  if (wf.in) {
+    // one chunk per wave, for as many chunks as a full queue has (of a short queue, cut into chunks of 16 rays, only
+    // RT_QUEUE_SMALL / 16 exist); a wave whose chunk lies beyond the queue's end leaves at once
+    const uint32_t chunks = wf.queue_cap < RT_QUEUE_SMALL ? (wf.queue_cap + 15u) / 16u : std::max(RT_QUEUE_SMALL / 16u, (wf.queue_cap + 63u) / 64u);
+    grid = dim3((chunks + RT_WBLOCK / 64 - 1) / (RT_WBLOCK / 64), 1); bounce = true;
   }
   RtWaveArgs A;
   A.tiles_x = grid.x; A.tiles_y = grid.y; A.strips_per_die = 0u;
@@ -1223,60 +1231,4 @@ void rt_launch_wave_kernel(const RtDeviceView& V, const RowMap& rows, bool bounc
     hipLaunchKernelGGL((render_wave<false, false, false, true>), grid, block, 0, stream, V.wnodes, V.tri_leaf, A);
   else LAUNCH(false, false, false);
 #undef LAUNCH
-}
-
-namespace {
-// One thread per term; the thread that holds the first term of a pixel adds up that pixel's terms in key order
-// (camera.cu:110-111: colour = colour + att * ray colour, starting from 0) and stores the pixel.
-__global__ __launch_bounds__(256) void resolve_terms(const unsigned long long* __restrict__ keys, const RtTermRGB* __restrict__ vals,
-                                                     uint32_t n, int path_bits, uint8_t* __restrict__ rgb) {
-  const uint32_t i = blockIdx.x * 256u + threadIdx.x;
-  if (i >= n) return;
-  const unsigned long long pixel = keys[i] >> path_bits;
-  if (i > 0u && (keys[i - 1] >> path_bits) == pixel) return;
-  float r = 0.f, g = 0.f, b = 0.f;
-  for (uint32_t j = i; j < n && (keys[j] >> path_bits) == pixel; j++) {
-    const RtTermRGB t = vals[j];
-    r = r + t.r; g = g + t.g; b = b + t.b;
-  }
-  uint8_t* dst = rgb + (size_t)pixel * 3;
-  dst[0] = rt_quantise(r); dst[1] = rt_quantise(g); dst[2] = rt_quantise(b);
-}
-}  // namespace
-
-namespace {
-__device__ __forceinline__ uint32_t spread3(uint32_t v) {   // 9 bits -> every third bit
-  v = (v | (v << 16)) & 0x030000ffu;
-  v = (v | (v << 8)) & 0x0300f00fu;
-  v = (v | (v << 4)) & 0x030c30c3u;
-  v = (v | (v << 2)) & 0x09249249u;
-  return v;
-}
-__global__ __launch_bounds__(256) void ray_keys(const RtQRay* __restrict__ rays, uint32_t n, float root_lo, float inv_cell, int octant_first,
-                                                uint32_t* __restrict__ keys, uint32_t* __restrict__ index) {
-  const uint32_t i = blockIdx.x * 256u + threadIdx.x;
-  if (i >= n) return;
-  const RtQRay& r = rays[i];
-  uint32_t cell[3];
-  for (int k = 0; k < 3; k++) {
-    const float g = (r.e[k] - root_lo) * inv_cell;
-    cell[k] = g > 0.f ? (g < 511.f ? (uint32_t)g : 511u) : 0u;   // (NaN -> 0)
-  }
-  const uint32_t oct = (r.d[0] < 0.f ? 1u : 0u) | (r.d[1] < 0.f ? 2u : 0u) | (r.d[2] < 0.f ? 4u : 0u);
-  const uint32_t morton = spread3(cell[0]) | (spread3(cell[1]) << 1) | (spread3(cell[2]) << 2);
-  keys[i] = octant_first ? ((oct << 27) | morton) : ((morton << 3) | oct);
-  index[i] = i;
-}
-}  // namespace
-
-void rt_launch_ray_keys(const RtQRay* rays, uint32_t n, float root_lo, float root_side, bool octant_first, uint32_t* keys, uint32_t* index,
-                        hipStream_t stream) {
-  if (n == 0) return;
-  hipLaunchKernelGGL(ray_keys, dim3((n + 255u) / 256u), dim3(256), 0, stream, rays, n, root_lo, 512.f / root_side, octant_first ? 1 : 0, keys,
-                     index);
-}
-
-void rt_launch_resolve_terms(const unsigned long long* keys, const RtTermRGB* vals, uint32_t n, int path_bits, uint8_t* rgb, hipStream_t stream) {
-  if (n == 0) return;
-  hipLaunchKernelGGL(resolve_terms, dim3((n + 255u) / 256u), dim3(256), 0, stream, keys, vals, n, path_bits, rgb);
 }

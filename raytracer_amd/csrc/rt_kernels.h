@@ -65,30 +65,52 @@ struct BounceRay {   // the fields of DRay that survive a push (vector.cu:188-20
 // material.cu:25-99).  The reference works it off a 10-entry LIFO stack per pixel and adds att * colour of every ray to
 // the pixel in the order the rays are processed.  Instead of keeping that stack inside one lane (whose wave then spends
 // dozens of dependent walks on a few pixels while the chip runs empty), every pushed ray can be appended to a queue and
-// the queue rendered by the next launch with 64 of them per wave.  What each ray contributes is appended to a term list
-// with a key that sorts the terms of a pixel into the reference's processing order; a last kernel adds them up in that
-// order, so the float sums, and the bytes, are the reference's.
-//   path: 4 bits per tree level, level 1 in the highest of the 4 * (ray depth limit) path bits; the digit of the k-th
-//         push of a ray is 15 - k, so that a ray
-//         pushed later (popped earlier by the LIFO stack) sorts first, a parent (shorter path, zero-padded) before its
-//         children, and a whole subtree before the next sibling: depth-first order, last pushed first = the stack's.
-struct RtQRay {   // 80 B
+// the queue rendered by the next launch with 64 of them per wave.
+//   * A pixel whose primary hit pushes a ray gets a BLOCK of term slots, one slot per node of its ray tree: with at most
+//     P pushes per hit and ray depth limit D the tree has 1 + P + ... + P^D nodes, the root in slot 0 and the k-th push
+//     (k = 0 .. P-1) of the ray in slot s in slot s * P + 1 + k.  Every ray writes its contribution att * colour into
+//     its own slot (each slot is written at most once per frame, by one lane: no atomics, no sort).
+//   * A last kernel adds up the slots of each block in the order the reference's stack processes the rays - depth first,
+//     of the rays pushed by one hit the last one first - so the float sums, and the bytes, are the reference's.
+//   * A slot is valid when its fourth word carries the frame's tag; stale slots of earlier frames do not (the pool is
+//     cleared when it is created and when the tag wraps), so nothing is cleared per frame.
+// Everything a generation needs to know about the one before it (how many rays, how many blocks) stays on the device:
+// the launches of a frame are enqueued back to back without a host round trip, and the one read-back at the end only
+// tells whether a queue or the block pool overflowed (the frame is then rendered on the lanes' stacks instead).
+struct RtQRay {   // 64 B
   float e[3], d[3], att[3], level[RT_MAX_LEVELS];
   int32_t nlevel, depth;
-  uint32_t pixel;     // position in the output buffer, in pixels
-  uint32_t pad;
-  unsigned long long path;
+  uint32_t block;     // the pixel's term block
+  uint32_t slot;      // this ray's node in the pixel's ray tree
 };
-struct RtTermRGB { float r, g, b, pad; };
-#define RT_PATH_MAX_PUSHES 15   // per ray
+static_assert(sizeof(RtQRay) == 64 && RT_MAX_LEVELS == 3, "queue record");
+struct RtTermRGB { float r, g, b; uint32_t tag; };
+struct RtQState {     // device-resident bookkeeping of a frame rendered from queues
+  uint32_t count[2];  // rays in queue 0 / 1 (may exceed the capacity: then `overflow` is set)
+  uint32_t n_blocks;  // term blocks handed out
+  uint32_t unused;
+  uint32_t overflow;  // a queue or the block pool was full
+  uint32_t box_lo[3], box_hi[3];   // box around the origins of the queue about to be rendered (floats in an order-preserving code)
+  uint32_t pad[5];
+};
+static_assert(sizeof(RtQState) == 64, "queue state");
+#define RT_TERM_SLOTS_MAX 128u   // nodes of a pixel's ray tree beyond which bounce rays stay on the lanes' stacks
+#define RT_QUEUE_SORT_MIN 4096u  // shorter queues are rendered in the order they were filled (`order` is not used)
+#define RT_QUEUE_SMALL 131072u   // shorter queues are rendered with 16 rays per wave instead of 64
 struct RtQueues {
-  const RtQRay* in; RtQRay* out; uint32_t* out_count;                 // in == nullptr: the pass that casts the primary rays
-  const uint32_t* order;                                              // lane i of the launch takes in[order[i]] (nullptr: in[i])
-  unsigned long long* term_keys; RtTermRGB* term_vals; uint32_t* term_count;
-  uint32_t n_in, out_cap, term_cap; int32_t enabled;
-  int32_t path_bits;   // 4 * ray depth limit: width of the path part of a term key, the pixel sits above it
-  int32_t rays_per_wave;   // 64, or 16 for a short queue: four times as many waves, each with a quarter of the walk
+  const RtQRay* in; RtQRay* out;          // in == nullptr: the pass that casts the primary rays
+  const uint32_t* order;                  // ray i of the launch is in[order[i]] (nullptr: in[i])
+  RtQState* state;
+  RtTermRGB* terms;                       // [slot][block], block_cap blocks per slot
+  uint32_t* block_pixel;                  // output position (in pixels) of a block's pixel
+  uint32_t in_index, out_index;           // which of state->count belongs to `in` / `out`
+  uint32_t queue_cap, block_cap;
+  uint32_t pushes;                        // P: most rays one hit can push (the fan-out of the slot numbering)
+  uint32_t tag;                           // of this frame's terms
+  int32_t enabled;
 };
+// Order in which a block's slots are added up: depth first, later pushes first (the LIFO stack's order); n <= RT_TERM_SLOTS_MAX.
+struct RtSlotOrder { uint8_t slot[RT_TERM_SLOTS_MAX]; uint32_t n; };
 
 // camera.cu:113-122: min(c, 1) * 255 truncated; NaN < 1 is false, so NaN -> 1 -> 255; negatives stored as 0
 __device__ __forceinline__ uint8_t rt_quantise(float c) {
@@ -144,17 +166,20 @@ void rt_launch_lane_kernel(const RtDeviceView& view, const RowMap& rows, bool bo
 // launch renders the rays of that queue instead of primary rays (rows, rgb, ids, ts unused).
 void rt_launch_wave_kernel(const RtDeviceView& view, const RowMap& rows, bool bounce, bool count, uint8_t* rgb, int32_t* ids,
                            float* ts, unsigned long long* counters, bool tally, const RtQueues& wf, hipStream_t stream);
-// Adds up the sorted terms of every pixel that has any, in key order, quantises and stores the pixel.
-hipError_t rt_sort_terms(void* temp, size_t* temp_bytes, const unsigned long long* keys_in, unsigned long long* keys_out,
-                         const RtTermRGB* vals_in, RtTermRGB* vals_out, uint32_t n, unsigned end_bit, hipStream_t stream);
-hipError_t rt_sort_u32(void* temp, size_t* temp_bytes, const uint32_t* keys_in, uint32_t* keys_out, const uint32_t* vals_in,
-                       uint32_t* vals_out, uint32_t n, unsigned end_bit, hipStream_t stream);
-// Coherence key of every queued ray (direction octant and Morton code of the origin on a 512^3 grid over the octree's
-// root cube, either of them in the high bits) and the identity permutation, to be sorted by key: waves then get rays
-// that start close together and head the same way, which is what the shared walk is good at.  Any order gives the
-// same image.
-void rt_launch_ray_keys(const RtQRay* rays, uint32_t n, float root_lo, float root_side, bool octant_first, uint32_t* keys, uint32_t* index,
-                        hipStream_t stream);
-void rt_launch_resolve_terms(const unsigned long long* keys, const RtTermRGB* vals, uint32_t n, int path_bits, uint8_t* rgb, hipStream_t stream);
+// Coherence order of a queue's rays (any order gives the same image; waves of rays that start close together and head
+// the same way are what the shared walk is good at): a counting sort on (direction octant, cell of the origin on a
+// 64^3 grid over the box around the origins themselves), all on the device - the number of rays is read from `state`.
+//   keys: one word per ray; bins: RT_QBINS words; sums: RT_QBIN_BLOCKS words; order: the sorted ray indices.
+#define RT_QCELL_BITS 6u
+#define RT_QBINS (8u << (3u * RT_QCELL_BITS))
+#define RT_QBIN_BLOCK 1024u
+#define RT_QBIN_BLOCKS (RT_QBINS / RT_QBIN_BLOCK)
+void rt_launch_ray_order(const RtQRay* rays, RtQState* state, uint32_t in_index, uint32_t queue_cap,
+                         uint32_t* keys, uint32_t* bins, uint32_t* sums, uint32_t* order, hipStream_t stream);
+// Between two generations: the queue that was just rendered becomes the next output queue (its count is cleared), the
+// box around the origins is emptied.
+void rt_launch_queue_advance(RtQState* state, uint32_t clear_index, hipStream_t stream);
+// Adds up the valid slots of every block in the stack's order, quantises and stores the pixel.
+void rt_launch_resolve_blocks(const RtQueues& q, const RtSlotOrder& order, uint8_t* rgb, hipStream_t stream);
 
 #endif
