@@ -328,16 +328,19 @@ int render_wavefront(const SceneArrays& S, RenderCtx& ctx, const RowMap& rows, b
   q.in = nullptr; q.out = queue[0]; q.order = nullptr; q.state = state;
   q.terms = (RtTermRGB*)(base + L.terms); q.block_pixel = (uint32_t*)(base + L.block_pixel);
   q.in_index = 1u; q.out_index = 0u; q.queue_cap = L.queue_cap; q.block_cap = L.block_cap; q.pushes = (uint32_t)p; q.tag = pool.tag; q.enabled = 1;
+  static const uint32_t small_below = getenv("RT_AMD_QUEUE_SMALL") ? (uint32_t)strtoul(getenv("RT_AMD_QUEUE_SMALL"), nullptr, 10) : RT_QUEUE_SMALL;   // measurements
+  q.small_below = small_below;
   rt_launch_wave_kernel(S.view, rows, true, count, d_rgb, d_ids, d_t, counters, tally, q, stream);
   HIP_TRY(hipGetLastError());
   static const bool sort_rays = !(getenv("RT_AMD_SORT_RAYS") && atoi(getenv("RT_AMD_SORT_RAYS")) == 0);   // measurements
+  static const uint32_t octant_first_min = getenv("RT_AMD_OCTANT_FIRST_MIN") ? (uint32_t)strtoul(getenv("RT_AMD_OCTANT_FIRST_MIN"), nullptr, 10) : 600000u;
   uint32_t cur = 0u;
   for (int gen = 1; gen <= D; gen++) {   // rays of depth `gen` (camera.cu:104-112 works them off one by one)
     rt_launch_queue_advance(state, cur ^ 1u, stream);
     q.in = queue[cur]; q.in_index = cur; q.out = queue[cur ^ 1u]; q.out_index = cur ^ 1u; q.order = nullptr;
     if (sort_rays && S.view.has_oct) {   // the queue is put in an order that keeps similar rays together
       uint32_t* const order = (uint32_t*)(base + L.order);
-      rt_launch_ray_order(queue[cur], state, cur, L.queue_cap, (uint32_t*)(base + L.keys), (uint32_t*)(base + L.bins),
+      rt_launch_ray_order(queue[cur], state, cur, L.queue_cap, octant_first_min, (uint32_t*)(base + L.keys), (uint32_t*)(base + L.bins),
                           (uint32_t*)(base + L.sums), order, stream);
       q.order = order;
     }

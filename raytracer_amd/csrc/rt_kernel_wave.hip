@@ -69,6 +69,72 @@ __device__ __forceinline__ float wave_min(float v) {
   return __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, fminf(fminf(r0, r1), fminf(r2, r3)))));
 }
 
+// The walk of a set of rays (`live`) that agree on their direction signs (`variant`: the copy of the node array whose plane
+// pairs are in (near, far) order for them; zpat 0) or share the pattern `zpat` of zero direction components (variant 0),
+// as one block of assembly - see the call in trace_wave for what the block does and which registers it owns.
+// `nodes` is that variant's array; the root's children start at record top_first, `rem` names the ones to test.
+// Returns the lanes that are still looking for a hit afterwards (shadow rays leave when they are known to be blocked).
+__device__ __forceinline__ uint64_t walk_asm(const float4* nodes, uint32_t variant, uint32_t zpat, const float4* tri_leaf, uint32_t top_first, uint32_t rem,
+                                             uint64_t live, const RtVec3& e, const RtVec3& d, const RtVec3& inv, const RtVec3& fc, float neg_eb,
+                                             float stop_t, Hit& hit, WaveStack& st, int lane) {
+  const RtVec3 c2 = {-d.x, -d.y, -d.z};                   // third column of the triangle solve (triangle.cu:118-120)
+  const v2f e_xy = {e.x, e.y}, c_zx = {c2.z, c2.x}, c_yz = {c2.y, c2.z}, c_yx = {c2.y, c2.x};
+  uint64_t a_blk = (uint64_t)(uintptr_t)(nodes + 2 * (size_t)top_first);
+  uint32_t a_rem = rem | 0x100u, a_first = top_first, a_idx = 0u, a_rfirst = 0u, a_rmeta = 0u, a_k = 0u, a_res = 0u, a_prim = 0u, a_sp = 0u;
+  uint64_t a_tmask = live, a_mine = live, a_live = live, a_acc = 0ull, a_und = 0ull, a_pass = 0ull, a_tp = 0ull, a_chg = 0ull;
+  const uint64_t a_nodes = (uint64_t)(uintptr_t)nodes, a_tri = (uint64_t)(uintptr_t)tri_leaf;
+  const uint32_t a_sign = 0x80000000u;
+  const float cmax = rt_max3(fabsf(fc.x), fabsf(fc.y), fabsf(fc.z));
+  float a_det = 0.f, a_nb = 0.f, a_ng = 0.f, a_nt = 0.f;
+  // (one copy of the block per kind of node test inside the one statement: sign-uniform rays (0), or the rays' common
+  //  zero pattern (1..6), chosen by s18)
+  for (;;) {
+    asm volatile(RT_TRACE_ASM
+        : "+{s[68:69]}"(a_blk), "+{s70}"(a_rem), "+{s71}"(a_first), "+{s[72:73]}"(a_tmask), "+{s[74:75]}"(a_mine), "+{s[76:77]}"(a_live),
+          "+{s78}"(a_idx), "+{s79}"(a_rfirst), "+{s80}"(a_rmeta), "+{s[94:95]}"(a_acc), "+{s[96:97]}"(a_und), "+{s[28:29]}"(a_pass),
+          "+{s[20:21]}"(a_tp), "+{s22}"(a_k), "+{s[24:25]}"(a_chg), "+{s30}"(a_res), "+{s31}"(a_prim), "+{m0}"(a_sp),
+          "+{v60}"(st.first), "+{v61}"(st.cur), "+{v62}"(st.mask_lo), "+{v63}"(st.mask_hi),
+          "={v32}"(a_det), "={v33}"(a_nb), "={v35}"(a_ng), "={v36}"(a_nt)
+        : "{s[82:83]}"(a_nodes), "{s[92:93]}"(a_tri), "{s23}"(a_sign), "{s18}"(zpat), "{v[40:41]}"(e_xy), "{v42}"(e.z), "{v[44:45]}"(c_zx), "{v[46:47]}"(c_yz),
+          "{v[48:49]}"(c_yx), "{v50}"(inv.x), "{v51}"(inv.y), "{v52}"(inv.z), "{v53}"(fc.x), "{v54}"(fc.y), "{v55}"(fc.z), "{v56}"(cmax),
+          "{v57}"(neg_eb), "{v58}"(hit.t), "{v59}"(stop_t)
+        : "s36", "s37", "s38", "s39", "s40", "s41", "s42", "s43", "s44", "s45", "s46", "s47", "s48", "s49", "s50", "s51", "s52", "s53", "s54", "s55",
+          "s56", "s57", "s58", "s59", "s60", "s61", "s62", "s63", "s64", "s65", "s66", "s67", "s81", "s84", "s85", "s86", "s87", "s88", "s89", "s90",
+          "s91", "s98", "s99", "s26", "s27", "v34", "v37", "v38", "v39", "v64", "v65", "v66", "v67", "v68", "v69", "v70", "v71", "v72", "v73", "v74",
+          "v75", "v76", "v77", "v78", "v79", "vcc", "scc");
+    if (a_res == 0u) break;
+    if (a_res == 1u) {
+      // the exact test for the lanes in a_und: the planes of the child just tested are read again
+      const uint32_t c_cur = (a_rmeta >> 24) & 7u;
+      typedef float f4 __attribute__((ext_vector_type(4)));
+      typedef const __attribute__((address_space(4))) f4* cnode_ptr;
+      auto rec = [](cnode_ptr q) { const f4 v = *q; return float4{v.x, v.y, v.z, v.w}; };
+      constexpr uint32_t NS = 2;
+      const cnode_ptr cb = (cnode_ptr)a_blk;
+      const float4 na = rec(cb + NS * c_cur), nb = rec(cb + NS * c_cur + 1);
+      RtVec3 dd = d, ee = e; float T = hit.t;
+      asm volatile("" : "+v"(dd.x), "+v"(dd.y), "+v"(dd.z), "+v"(ee.x), "+v"(ee.y), "+v"(ee.z), "+v"(T));
+      const RtRayConst rc = rt_ray_const(dd);
+      const bool wx = (variant & 1u) != 0u, wy = (variant & 2u) != 0u, wz = (variant & 4u) != 0u;
+      const RtVec3 ini = {wx ? na.y : na.x, wy ? na.w : na.z, wz ? nb.x : nb.y}, end = {wx ? na.x : na.y, wy ? na.z : na.w, wz ? nb.y : nb.x};
+      const float S = rt_node_score(ini, end, ee, dd, rc, rt_t_float(rc, T));
+      uint64_t pos_m = __builtin_amdgcn_ballot_w64(S > 0.f);
+      const uint64_t tie_m = __builtin_amdgcn_ballot_w64(S == 0.f) & a_und;
+      if (tie_m) {   // a boundary case: settle it with the compare form
+        const bool ex = rt_node_accept_exact(ini, end, ee, dd, rc, rt_t_const(rc, T));
+        pos_m = (pos_m & ~tie_m) | (__builtin_amdgcn_ballot_w64(ex) & tie_m);
+      }
+      a_acc |= pos_m & a_und;
+    } else if ((a_pass >> lane) & 1ull) {   // the reference's quotients decide (triangle.cu:131-137)
+      RtTriNum n;
+      n.det = a_det; n.nb = a_nb; n.ng = a_ng; n.nt = a_nt;
+      float t, bet, gam;
+      if (rt_triangle_finish(n, hit.t, t, bet, gam)) { hit.t = t; hit.prim = (int32_t)a_prim; hit.bet = bet; hit.gam = gam; }
+    }
+  }
+  return a_live;
+}
+
 // Closest hit (ray.cu:29-54) for all lanes of the wave at once.
 //   want   : this lane has a ray to trace
 //   stop_t : >= 0 for a shadow ray: the lane drops out as soon as its t falls below stop_t, because
@@ -201,56 +267,7 @@ __device__ __forceinline__ void trace_wave(const float4* __restrict__ nodes, int
     // closest hit so far, shadow-ray length), v[60:63] the wave's stack, v32 v33 v35 v36 determinant and numerators
     // of a candidate, v34 v37:v39 v64:v79 scratch.
     if ((presorted || zpat != 0u) && FUSED && (rem & 0xffu) != 0u) {
-      uint64_t a_blk = (uint64_t)(uintptr_t)(nodes + NS * (size_t)top_first);
-      uint32_t a_rem = rem | 0x100u, a_first = top_first, a_idx = 0u, a_rfirst = 0u, a_rmeta = 0u, a_k = 0u, a_res = 0u, a_prim = 0u, a_sp = 0u;
-      uint64_t a_tmask = live, a_mine = live, a_live = live, a_acc = 0ull, a_und = 0ull, a_pass = 0ull, a_tp = 0ull, a_chg = 0ull;
-      const uint64_t a_nodes = (uint64_t)(uintptr_t)nodes, a_tri = (uint64_t)(uintptr_t)tri_leaf;
-      const uint32_t a_sign = 0x80000000u;
-      const float cmax = rt_max3(fabsf(fc.x), fabsf(fc.y), fabsf(fc.z));
-      float a_det = 0.f, a_nb = 0.f, a_ng = 0.f, a_nt = 0.f;
-      // (one copy of the block per kind of node test inside the one statement: sign-uniform rays (0), or the rays' common
-      //  zero pattern (1..6), chosen by s18)
-      for (;;) {
-        asm volatile(RT_TRACE_ASM
-            : "+{s[68:69]}"(a_blk), "+{s70}"(a_rem), "+{s71}"(a_first), "+{s[72:73]}"(a_tmask), "+{s[74:75]}"(a_mine), "+{s[76:77]}"(a_live),
-              "+{s78}"(a_idx), "+{s79}"(a_rfirst), "+{s80}"(a_rmeta), "+{s[94:95]}"(a_acc), "+{s[96:97]}"(a_und), "+{s[28:29]}"(a_pass),
-              "+{s[20:21]}"(a_tp), "+{s22}"(a_k), "+{s[24:25]}"(a_chg), "+{s30}"(a_res), "+{s31}"(a_prim), "+{m0}"(a_sp),
-              "+{v60}"(st.first), "+{v61}"(st.cur), "+{v62}"(st.mask_lo), "+{v63}"(st.mask_hi),
-              "={v32}"(a_det), "={v33}"(a_nb), "={v35}"(a_ng), "={v36}"(a_nt)
-            : "{s[82:83]}"(a_nodes), "{s[92:93]}"(a_tri), "{s23}"(a_sign), "{s18}"(zpat), "{v[40:41]}"(e_xy), "{v42}"(e.z), "{v[44:45]}"(c_zx), "{v[46:47]}"(c_yz),
-              "{v[48:49]}"(c_yx), "{v50}"(inv.x), "{v51}"(inv.y), "{v52}"(inv.z), "{v53}"(fc.x), "{v54}"(fc.y), "{v55}"(fc.z), "{v56}"(cmax),
-              "{v57}"(neg_eb), "{v58}"(hit.t), "{v59}"(stop_t)
-            : "s36", "s37", "s38", "s39", "s40", "s41", "s42", "s43", "s44", "s45", "s46", "s47", "s48", "s49", "s50", "s51", "s52", "s53", "s54", "s55",
-              "s56", "s57", "s58", "s59", "s60", "s61", "s62", "s63", "s64", "s65", "s66", "s67", "s81", "s84", "s85", "s86", "s87", "s88", "s89", "s90",
-              "s91", "s98", "s99", "s26", "s27", "v34", "v37", "v38", "v39", "v64", "v65", "v66", "v67", "v68", "v69", "v70", "v71", "v72", "v73", "v74",
-              "v75", "v76", "v77", "v78", "v79", "vcc", "scc");
-        if (a_res == 0u) break;
-        if (a_res == 1u) {
-          // the exact test for the lanes in a_und: the planes of the child just tested are read again
-          const uint32_t c_cur = (a_rmeta >> 24) & 7u;
-          const cnode_ptr cb = (cnode_ptr)a_blk;
-          const float4 na = rec(cb + NS * c_cur), nb = rec(cb + NS * c_cur + 1);
-          RtVec3 dd = d, ee = e; float T = hit.t;
-          asm volatile("" : "+v"(dd.x), "+v"(dd.y), "+v"(dd.z), "+v"(ee.x), "+v"(ee.y), "+v"(ee.z), "+v"(T));
-          const RtRayConst rc = rt_ray_const(dd);
-          const bool wx = (variant & 1u) != 0u, wy = (variant & 2u) != 0u, wz = (variant & 4u) != 0u;
-          const RtVec3 ini = {wx ? na.y : na.x, wy ? na.w : na.z, wz ? nb.x : nb.y}, end = {wx ? na.x : na.y, wy ? na.z : na.w, wz ? nb.y : nb.x};
-          const float S = rt_node_score(ini, end, ee, dd, rc, rt_t_float(rc, T));
-          uint64_t pos_m = __builtin_amdgcn_ballot_w64(S > 0.f);
-          const uint64_t tie_m = __builtin_amdgcn_ballot_w64(S == 0.f) & a_und;
-          if (tie_m) {   // a boundary case: settle it with the compare form
-            const bool ex = rt_node_accept_exact(ini, end, ee, dd, rc, rt_t_const(rc, T));
-            pos_m = (pos_m & ~tie_m) | (__builtin_amdgcn_ballot_w64(ex) & tie_m);
-          }
-          a_acc |= pos_m & a_und;
-        } else if ((a_pass >> lane) & 1ull) {   // the reference's quotients decide (triangle.cu:131-137)
-          RtTriNum n;
-          n.det = a_det; n.nb = a_nb; n.ng = a_ng; n.nt = a_nt;
-          float t, bet, gam;
-          if (rt_triangle_finish(n, hit.t, t, bet, gam)) { hit.t = t; hit.prim = (int32_t)a_prim; hit.bet = bet; hit.gam = gam; }
-        }
-      }
-      live = a_live;
+      live = walk_asm(nodes, variant, zpat, tri_leaf, top_first, rem, live, e, d, inv, fc, neg_eb, stop_t, hit, st, lane);
       if (!live) return;
     } else {
 #endif
@@ -688,6 +705,60 @@ __device__ __forceinline__ void trace_wave(const float4* __restrict__ nodes, int
   }
 }
 
+// Closest hit through the assembly walk for one class of the wave's pending rays (the production variants without bounce
+// rays).  The walk wants rays that agree on their direction signs, or share a pattern of zero direction components; of a
+// wave whose rays do not (the tiles on the picture's centre lines, a few shadow waves) only the class of the first
+// pending lane is traced.  Returns the lanes that were traced; the others keep their rays for the caller's next round.
+// A lane's result never depends on which other lanes walk with it, so the hits are those of any other grouping.
+// A direction component so small that its inverse overflows (or a NaN) cannot feed the fused plane distances: such a
+// lane walks with a NaN inverse direction, which the conservative classification can decide nothing about - every node
+// test of the lane goes to the exact test, which does not use the inverse.
+__device__ __forceinline__ uint64_t trace_class(const float4* __restrict__ nodes, int n_wnodes, const float4* __restrict__ tri_leaf,
+                                                const RtSphere* __restrict__ spheres, int n_spheres, bool has_oct, bool want,
+                                                const RtVec3& e, const RtVec3& d, float stop_t, Hit& hit, WaveStack& st, int lane) {
+  const uint64_t pending = __builtin_amdgcn_ballot_w64(want);
+  if (!pending) return 0ull;
+  uint64_t cls = pending, after = pending;
+  if (has_oct) {
+    typedef float f4 __attribute__((ext_vector_type(4)));
+    typedef const __attribute__((address_space(4))) f4* cnode_ptr;
+    const f4 root_b = *((cnode_ptr)(uintptr_t)nodes + 1);   // (links and child mask of the root are the same in every variant)
+    const uint32_t top_first = uni(__float_as_uint(root_b.z)), rem = uni(__float_as_uint(root_b.w)) & 0xffu;
+    if (rem != 0u) {
+      RtVec3 inv = {1.f / d.x, 1.f / d.y, 1.f / d.z};   // only feeds the conservative classification
+      unsigned zmask = (d.x == 0.f ? 1u : 0u) | (d.y == 0.f ? 2u : 0u) | (d.z == 0.f ? 4u : 0u);
+      const float INF = __builtin_inff();
+      const bool unusable = zmask == 7u || (!(zmask & 1u) && !(fabsf(inv.x) < INF)) || (!(zmask & 2u) && !(fabsf(inv.y) < INF)) ||
+                            (!(zmask & 4u) && !(fabsf(inv.z) < INF));
+      if (unusable) { const float nan = __builtin_nanf(""); inv = {nan, nan, nan}; if (zmask == 7u) zmask = 0u; }
+      // class of a lane: its zero pattern if it has one (the signs of the other components may differ within a class),
+      // else its three direction signs
+      const uint32_t key = zmask ? (8u | zmask) : ((d.x < 0.f ? 1u : 0u) | (d.y < 0.f ? 2u : 0u) | (d.z < 0.f ? 4u : 0u));
+      const uint32_t k0 = (uint32_t)__builtin_amdgcn_readlane((int)key, __builtin_ctzll(pending));
+      cls = __builtin_amdgcn_ballot_w64(key == k0) & pending;
+      const uint32_t zpat = (k0 & 8u) ? (k0 & 7u) : 0u, variant = (k0 & 8u) ? 0u : k0;
+      const float4* const vnodes = nodes + 2 * (size_t)variant * (size_t)n_wnodes;   // each variant is a dense copy of the whole array
+      const RtSlabFused fu = rt_slab_fused(e, inv);
+      float neg_eb = 0.f;
+      if (zpat == 0u) {   // margin that no node of this tree exceeds for this ray (the root's planes bound every node's)
+        const f4 ra = *(cnode_ptr)(uintptr_t)vnodes, rb = *((cnode_ptr)(uintptr_t)vnodes + 1);
+        neg_eb = -rt_slab_margin_bound_fused(ra.x, ra.y, ra.z, ra.w, rb.x, rb.y, e, inv, fu, hit.t);
+      }
+      after = walk_asm(vnodes, variant, zpat, tri_leaf, top_first, rem, cls, e, d, inv, fu.c, neg_eb, stop_t, hit, st, lane);
+    }
+  }
+  if (n_spheres > 0 && after) {
+    bool mine_live = ((after >> lane) & 1ull) != 0ull;
+    for (int32_t s = 0; s < n_spheres; s++) {   // ray.cu:52-53
+      if (mine_live && rt_sphere_test(ld3(spheres[s].c), spheres[s].r, e, d, hit.t)) {
+        hit.prim = -2 - s;
+        if (stop_t >= 0.f && hit.t < stop_t) mine_live = false;
+      }
+    }
+  }
+  return cls;
+}
+
 enum { PH_CLOSEST = 0, PH_SHADOW = 1, PH_DONE = 2, PH_SHADE = 3 };
 
 #ifndef RT_WAVES_PER_SIMD_BOUNCE
@@ -865,6 +936,13 @@ __global__ __launch_bounds__(RT_WBLOCK, BOUNCE ? RT_WAVES_PER_SIMD_BOUNCE : (DEN
   float tr_stop = -1.f;     // >= 0: shadow ray, length to the light
   int phase;
   const bool wavefront = BOUNCE && QUEUES;                    // bounce rays leave through the queue
+  // every ray through the assembly walk, class by class (trace_class)?  Where rays scatter (bounce rays rendered from
+  // queues in the order they were filled), one shared general walk of a mixed wave is the better deal.
+#ifdef RT_NO_ASM_WALK
+  constexpr bool CLASSES = false;
+#else
+  constexpr bool CLASSES = !BOUNCE && !COUNT && !RT_PATHS_ON;
+#endif
   const bool queued = BOUNCE && QUEUES && A.wf.in != nullptr;   // this launch renders a queue of bounce rays, one per lane
   if (!queued) {
     const Pixel px0 = pixel_of(tid);
@@ -942,7 +1020,7 @@ __global__ __launch_bounds__(RT_WBLOCK, BOUNCE ? RT_WAVES_PER_SIMD_BOUNCE : (DEN
     n_in = n_in < wf.queue_cap ? n_in : wf.queue_cap;
     n_in = __builtin_amdgcn_readfirstlane(n_in);
     // a short queue: shorter walks in four times as many waves (measured break-even)
-    const uint32_t per_wave = n_in < RT_QUEUE_SMALL ? 16u : 64u;
+    const uint32_t per_wave = n_in < wf.small_below ? 16u : 64u;
     const uint32_t chunk = blockIdx.x * (RT_WBLOCK / 64) + (uint32_t)(tid >> 6);
     if ((unsigned long long)chunk * per_wave >= n_in) return;
     const uint32_t gid = chunk * per_wave + lane;
@@ -959,18 +1037,19 @@ __global__ __launch_bounds__(RT_WBLOCK, BOUNCE ? RT_WAVES_PER_SIMD_BOUNCE : (DEN
   while (__builtin_amdgcn_ballot_w64(phase != PH_DONE)) {
     // ---- trace the pending rays of the wave ---------------------------------------------------------
     Hit h = {RT_INF, -1, 0.f, 0.f};
+    bool traced = phase != PH_DONE;   // (trace_class may leave some of the wave's rays for the next round)
     {
       const bool want = phase != PH_DONE;
       // the instrumented variant walks shadow rays to the end, as the reference does, so that its test counts match
       const float stop_t = (phase == PH_SHADOW && !COUNT) ? tr_stop : -1.f;
-      if (want) tl.traced++;
       park<BOUNCE>(sh, my_park);
       {   // the ray counters of the lane wait out the walk in LDS too (else they are spilled around it where registers are short)
         uint32_t* pk = (uint32_t*)my_park + ShadeState<BOUNCE>::WORDS * RT_WBLOCK;
         pk[0] = tl.rays; pk[RT_WBLOCK] = tl.shadow; pk[2 * RT_WBLOCK] = tl.traced;
       }
       asm volatile("" ::: "memory");
-      trace_wave<COUNT>(nodes, n_wnodes, tri_leaf, spheres, n_spheres, has_oct != 0, want, tr_e, tr_d, stop_t, h, st, lane, tl, cull_sh + 16 * (tid >> 6));
+      if (CLASSES) traced = ((trace_class(nodes, n_wnodes, tri_leaf, spheres, n_spheres, has_oct != 0, want, tr_e, tr_d, stop_t, h, st, lane) >> lane) & 1ull) != 0ull;
+      else trace_wave<COUNT>(nodes, n_wnodes, tri_leaf, spheres, n_spheres, has_oct != 0, want, tr_e, tr_d, stop_t, h, st, lane, tl, cull_sh + 16 * (tid >> 6));
       asm volatile("" ::: "memory");
       unpark<BOUNCE>(sh, my_park);
       {
@@ -978,8 +1057,10 @@ __global__ __launch_bounds__(RT_WBLOCK, BOUNCE ? RT_WAVES_PER_SIMD_BOUNCE : (DEN
         tl.rays = pk[0]; tl.shadow = pk[RT_WBLOCK]; tl.traced = pk[2 * RT_WBLOCK];
       }
     }
+    if (traced) tl.traced++;
     const rt_kernarg_ptr ka = late_args();   // one opaque copy for the whole shading phase: its loads go out together
-    if (phase == PH_CLOSEST) {
+    if (!traced) {
+    } else if (phase == PH_CLOSEST) {
       if (primary) {
         primary = false;
         int32_t* const ids = LATE_AT(ka, ids); float* const ts = LATE_AT(ka, ts);
@@ -1010,7 +1091,7 @@ __global__ __launch_bounds__(RT_WBLOCK, BOUNCE ? RT_WAVES_PER_SIMD_BOUNCE : (DEN
       verdict = tr_stop > h.t ? 1 : 0;   // ray.cu:70; consumed by the (material, light) step that asked for it
     }
     // ---- shade until the lane needs another ray or its pixel is finished --------------------------------
-    if (phase != PH_DONE) {
+    if (traced) {
       phase = PH_SHADE;
       while (phase == PH_SHADE) {
         if (sh.mi >= sh.mcount) {   // every material of the hit handled: camera.cu:110-111, then next ray of the pixel
@@ -1194,7 +1275,7 @@ void rt_launch_wave_kernel(const RtDeviceView& V, const RowMap& rows, bool bounc
   if (wf.in) {
     // one chunk per wave, for as many chunks as a full queue has (of a short queue, cut into chunks of 16 rays, only
     // RT_QUEUE_SMALL / 16 exist); a wave whose chunk lies beyond the queue's end leaves at once
-    const uint32_t chunks = wf.queue_cap < RT_QUEUE_SMALL ? (wf.queue_cap + 15u) / 16u : std::max(RT_QUEUE_SMALL / 16u, (wf.queue_cap + 63u) / 64u);
+    const uint32_t chunks = wf.queue_cap < wf.small_below ? (wf.queue_cap + 15u) / 16u : std::max(wf.small_below / 16u, (wf.queue_cap + 63u) / 64u);
     grid = dim3((chunks + RT_WBLOCK / 64 - 1) / (RT_WBLOCK / 64), 1); bounce = true;
   }
   RtWaveArgs A;

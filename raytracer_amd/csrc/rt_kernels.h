@@ -107,6 +107,7 @@ struct RtQueues {
   uint32_t queue_cap, block_cap;
   uint32_t pushes;                        // P: most rays one hit can push (the fan-out of the slot numbering)
   uint32_t tag;                           // of this frame's terms
+  uint32_t small_below;                   // queues shorter than this are rendered with 16 rays per wave instead of 64
   int32_t enabled;
 };
 // Order in which a block's slots are added up: depth first, later pushes first (the LIFO stack's order); n <= RT_TERM_SLOTS_MAX.
@@ -174,7 +175,7 @@ void rt_launch_wave_kernel(const RtDeviceView& view, const RowMap& rows, bool bo
 #define RT_QBINS (8u << (3u * RT_QCELL_BITS))
 #define RT_QBIN_BLOCK 1024u
 #define RT_QBIN_BLOCKS (RT_QBINS / RT_QBIN_BLOCK)
-void rt_launch_ray_order(const RtQRay* rays, RtQState* state, uint32_t in_index, uint32_t queue_cap,
+void rt_launch_ray_order(const RtQRay* rays, RtQState* state, uint32_t in_index, uint32_t queue_cap, uint32_t octant_first_min,
                          uint32_t* keys, uint32_t* bins, uint32_t* sums, uint32_t* order, hipStream_t stream);
 // Between two generations: the queue that was just rendered becomes the next output queue (its count is cleared), the
 // box around the origins is emptied.

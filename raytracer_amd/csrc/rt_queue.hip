@@ -82,7 +82,7 @@ __global__ __launch_bounds__(QBLOCK) void q_bounds(const RtQRay* __restrict__ ra
 }
 
 // Pass 1: the key of every ray, and how many rays each key has.
-__global__ __launch_bounds__(QBLOCK) void q_keys(const RtQRay* __restrict__ rays, const RtQState* __restrict__ state, uint32_t in_index, uint32_t queue_cap,
+__global__ __launch_bounds__(QBLOCK) void q_keys(const RtQRay* __restrict__ rays, const RtQState* __restrict__ state, uint32_t in_index, uint32_t queue_cap, uint32_t octant_first_min,
                                                  uint32_t* __restrict__ keys, uint32_t* __restrict__ bins) {
   const uint32_t n = ray_count(state, in_index, queue_cap);
   if (n < RT_QUEUE_SORT_MIN) return;
@@ -98,7 +98,7 @@ __global__ __launch_bounds__(QBLOCK) void q_keys(const RtQRay* __restrict__ rays
   }
   // with a million rays a generation grouping by octant first gives the better waves, with fewer grouping by origin first
   // (measured on the glass bunny at 4K and at 720p / 1080p)
-  const bool octant_first = n >= 600000u;
+  const bool octant_first = n >= octant_first_min;
   const uint32_t rounds = (n + QGRID * QBLOCK - 1u) / (QGRID * QBLOCK);
   for (uint32_t r = 0; r < rounds; r++) {   // whole waves take part in every round (the grouping ballots)
     const uint32_t i = (r * QGRID + blockIdx.x) * QBLOCK + threadIdx.x;
@@ -223,11 +223,11 @@ __global__ __launch_bounds__(QBLOCK) void q_resolve(const RtQState* __restrict__
 
 }  // namespace
 
-void rt_launch_ray_order(const RtQRay* rays, RtQState* state, uint32_t in_index, uint32_t queue_cap,
+void rt_launch_ray_order(const RtQRay* rays, RtQState* state, uint32_t in_index, uint32_t queue_cap, uint32_t octant_first_min,
                          uint32_t* keys, uint32_t* bins, uint32_t* sums, uint32_t* order, hipStream_t stream) {
   hipLaunchKernelGGL(q_bounds, dim3(BGRID), dim3(QBLOCK), 0, stream, rays, state, in_index, queue_cap);
   (void)hipMemsetAsync(bins, 0, (size_t)RT_QBINS * sizeof(uint32_t), stream);
-  hipLaunchKernelGGL(q_keys, dim3(QGRID), dim3(QBLOCK), 0, stream, rays, (const RtQState*)state, in_index, queue_cap, keys, bins);
+  hipLaunchKernelGGL(q_keys, dim3(QGRID), dim3(QBLOCK), 0, stream, rays, (const RtQState*)state, in_index, queue_cap, octant_first_min, keys, bins);
   hipLaunchKernelGGL(q_scan_blocks, dim3(RT_QBIN_BLOCKS), dim3(QBLOCK), 0, stream, bins, sums);
   hipLaunchKernelGGL(q_scan_sums, dim3(1), dim3(1024), 0, stream, sums);
   hipLaunchKernelGGL(q_scan_bins, dim3(RT_QBIN_BLOCKS), dim3(QBLOCK), 0, stream, bins, sums);
