@@ -69,6 +69,10 @@ __device__ __forceinline__ float wave_min(float v) {
   return __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, fminf(fminf(r0, r1), fminf(r2, r3)))));
 }
 
+// Is this lane in the wave-uniform set `mask`?  (The mask becomes the lane predicate directly; a shift by the lane number
+// would keep a 64-bit per-lane value alive wherever it is used.)
+__device__ __forceinline__ bool in_mask(uint64_t mask) { return __builtin_amdgcn_inverse_ballot_w64(mask); }
+
 // The walk of a set of rays (`live`) that agree on their direction signs (`variant`: the copy of the node array whose plane
 // pairs are in (near, far) order for them; zpat 0) or share the pattern `zpat` of zero direction components (variant 0),
 // as one block of assembly - see the call in trace_wave for what the block does and which registers it owns.
@@ -125,7 +129,7 @@ __device__ __forceinline__ uint64_t walk_asm(const float4* nodes, uint32_t varia
         pos_m = (pos_m & ~tie_m) | (__builtin_amdgcn_ballot_w64(ex) & tie_m);
       }
       a_acc |= pos_m & a_und;
-    } else if ((a_pass >> lane) & 1ull) {   // the reference's quotients decide (triangle.cu:131-137)
+    } else if (in_mask(a_pass)) {   // the reference's quotients decide (triangle.cu:131-137)
       RtTriNum n;
       n.det = a_det; n.nb = a_nb; n.ng = a_ng; n.nt = a_nt;
       float t, bet, gam;
@@ -748,7 +752,7 @@ __device__ __forceinline__ uint64_t trace_class(const float4* __restrict__ nodes
     }
   }
   if (n_spheres > 0 && after) {
-    bool mine_live = ((after >> lane) & 1ull) != 0ull;
+    bool mine_live = in_mask(after);
     for (int32_t s = 0; s < n_spheres; s++) {   // ray.cu:52-53
       if (mine_live && rt_sphere_test(ld3(spheres[s].c), spheres[s].r, e, d, hit.t)) {
         hit.prim = -2 - s;
@@ -784,14 +788,14 @@ struct ShadeState {
     return i == 0 ? a : (i == 1 ? b : c);
   }
   __device__ __forceinline__ void set_level(int i, float v) { level0 = i == 0 ? v : level0; level1 = i == 1 ? v : level1; level2 = i == 2 ? v : level2; }
-  static constexpr int WORDS = BOUNCE ? 30 : 22;
+  static constexpr int WORDS = BOUNCE ? 30 : 19;   // (without bounce rays the pixel's colour is not carried: its one ray finishes it)
 };
 
 // One statement per word (no temporary array: the state has to stay in registers on both sides).
 #define RT_SHADE_FLOATS(X) X(0, P.x) X(1, P.y) X(2, P.z) X(3, N.x) X(4, N.y) X(5, N.z) X(6, view.x) X(7, view.y) X(8, view.z) \
-  X(9, colr.x) X(10, colr.y) X(11, colr.z) X(12, color.x) X(13, color.y) X(14, color.z) X(15, hit_t)
-#define RT_SHADE_INTS(X) X(16, mfirst) X(17, mcount) X(18, mi) X(19, li) X(20, vis_known) X(21, vis_occluded)
-#define RT_SHADE_BOUNCE_FLOATS(X) X(22, att.x) X(23, att.y) X(24, att.z) X(25, level0) X(26, level1) X(27, level2)
+  X(9, colr.x) X(10, colr.y) X(11, colr.z) X(12, hit_t)
+#define RT_SHADE_INTS(X) X(13, mfirst) X(14, mcount) X(15, mi) X(16, li) X(17, vis_known) X(18, vis_occluded)
+#define RT_SHADE_BOUNCE_FLOATS(X) X(19, att.x) X(20, att.y) X(21, att.z) X(22, level0) X(23, level1) X(24, level2) X(25, color.x) X(26, color.y) X(27, color.z)
 #define RT_SHADE_BOUNCE_INTS(X) X(28, nlevel) X(29, depth)
 template <bool BOUNCE>
 __device__ __forceinline__ void park(const ShadeState<BOUNCE>& s, float* lds) {
@@ -866,13 +870,20 @@ __global__ __launch_bounds__(RT_WBLOCK, BOUNCE ? RT_WAVES_PER_SIMD_BOUNCE : (DEN
   const RtSphere* __restrict__ spheres = A.spheres;
   const int n_spheres = A.n_spheres, has_oct = A.has_oct, n_wnodes = A.n_wnodes;
   auto counters_ptr = [&]() { return LATE(counters_all) + ((blockIdx.x + blockIdx.y) & (RT_COUNTER_COPIES - 1)) * RT_COUNTER_STRIDE; };
-  // LDS of a workgroup: the parked shading state and the lane's three ray counters; the packing area of the epilogue
-  // lies over the same bytes (nothing is parked any more then).  25 words per lane = 6 400 B per wave keeps 24 waves per
-  // compute unit (six per SIMD) within the 160 KB.
-  __shared__ float parked[(ShadeState<BOUNCE>::WORDS + 3) * RT_WBLOCK];
+  // LDS of a workgroup: the parked shading state, the lane's three ray counters and its finished colour; the packing area
+  // of the epilogue lies over the first word of the state (nothing is parked any more then).  23 words per lane = 5 888 B
+  // per wave (without bounce rays) leaves room for 24 waves per compute unit (six per SIMD) in the 160 KB.
+  // The counters and the finished colour only ever live there: they are touched a few times per pixel, and as values that
+  // every round of the main loop carries along they cost six registers (in the six-wave variant: six spill stores per
+  // round) for nothing.
+  __shared__ float parked[(ShadeState<BOUNCE>::WORDS + 4) * RT_WBLOCK];
   uint32_t (*pack)[48] = (uint32_t (*)[48])parked;   // [wave][48]
   const int tid = threadIdx.x, lane = tid & 63;
   float* my_park = &parked[tid];
+  uint32_t* const my_counts = (uint32_t*)my_park + ShadeState<BOUNCE>::WORDS * RT_WBLOCK;   // rays, shadow rays, rays traced, finished colour
+  my_counts[0] = 0u; my_counts[RT_WBLOCK] = 0u; my_counts[2 * RT_WBLOCK] = 0u; my_counts[3 * RT_WBLOCK] = 0u;
+  enum { N_RAYS = 0, N_SHADOW = 1, N_TRACED = 2 };
+  auto count = [&](int which) { __hip_atomic_fetch_add(my_counts + which * RT_WBLOCK, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); };
   __shared__ float cull_sh[16 * (RT_WBLOCK / 64)];   // bounds of the wave's rays during a walk (trace_wave)
   WaveStack st = {0u, 0u, 0u, 0u};
   // Pixel of a thread: wave w of the block owns the 8x8 tile (w % RT_WAVES_X, w / RT_WAVES_X) of the block's pixels.  The
@@ -1030,7 +1041,7 @@ __global__ __launch_bounds__(RT_WBLOCK, BOUNCE ? RT_WAVES_PER_SIMD_BOUNCE : (DEN
       tr_e = ld3(q.e); tr_d = ld3(q.d); sh.att = ld3(q.att);
       sh.level0 = q.level[0]; sh.level1 = q.level[1]; sh.level2 = q.level[2]; sh.nlevel = q.nlevel; sh.depth = q.depth;
       q_block = q.block; q_slot = q.slot;
-      phase = PH_CLOSEST; tl.rays++;
+      phase = PH_CLOSEST; count(N_RAYS);
     }
     sh.view = tr_d;
   }
@@ -1043,21 +1054,13 @@ __global__ __launch_bounds__(RT_WBLOCK, BOUNCE ? RT_WAVES_PER_SIMD_BOUNCE : (DEN
       // the instrumented variant walks shadow rays to the end, as the reference does, so that its test counts match
       const float stop_t = (phase == PH_SHADOW && !COUNT) ? tr_stop : -1.f;
       park<BOUNCE>(sh, my_park);
-      {   // the ray counters of the lane wait out the walk in LDS too (else they are spilled around it where registers are short)
-        uint32_t* pk = (uint32_t*)my_park + ShadeState<BOUNCE>::WORDS * RT_WBLOCK;
-        pk[0] = tl.rays; pk[RT_WBLOCK] = tl.shadow; pk[2 * RT_WBLOCK] = tl.traced;
-      }
       asm volatile("" ::: "memory");
-      if (CLASSES) traced = ((trace_class(nodes, n_wnodes, tri_leaf, spheres, n_spheres, has_oct != 0, want, tr_e, tr_d, stop_t, h, st, lane) >> lane) & 1ull) != 0ull;
+      if (CLASSES) traced = in_mask(trace_class(nodes, n_wnodes, tri_leaf, spheres, n_spheres, has_oct != 0, want, tr_e, tr_d, stop_t, h, st, lane));
       else trace_wave<COUNT>(nodes, n_wnodes, tri_leaf, spheres, n_spheres, has_oct != 0, want, tr_e, tr_d, stop_t, h, st, lane, tl, cull_sh + 16 * (tid >> 6));
       asm volatile("" ::: "memory");
       unpark<BOUNCE>(sh, my_park);
-      {
-        const uint32_t* pk = (const uint32_t*)my_park + ShadeState<BOUNCE>::WORDS * RT_WBLOCK;
-        tl.rays = pk[0]; tl.shadow = pk[RT_WBLOCK]; tl.traced = pk[2 * RT_WBLOCK];
-      }
     }
-    if (traced) tl.traced++;
+    if (traced) count(N_TRACED);
     const rt_kernarg_ptr ka = late_args();   // one opaque copy for the whole shading phase: its loads go out together
     if (!traced) {
     } else if (phase == PH_CLOSEST) {
@@ -1103,6 +1106,12 @@ __global__ __launch_bounds__(RT_WBLOCK, BOUNCE ? RT_WAVES_PER_SIMD_BOUNCE : (DEN
             phase = PH_DONE;
             break;
           }
+          if (!BOUNCE) {   // the pixel's only ray: its bytes wait in LDS for the end of the wave
+            const float cx = 0.f + sh.att.x * sh.colr.x, cy = 0.f + sh.att.y * sh.colr.y, cz = 0.f + sh.att.z * sh.colr.z;
+            my_counts[3 * RT_WBLOCK] = (uint32_t)rt_quantise(cx) | ((uint32_t)rt_quantise(cy) << 8) | ((uint32_t)rt_quantise(cz) << 16);
+            phase = PH_DONE;
+            break;
+          }
           sh.color.x = sh.color.x + sh.att.x * sh.colr.x;
           sh.color.y = sh.color.y + sh.att.y * sh.colr.y;
           sh.color.z = sh.color.z + sh.att.z * sh.colr.z;
@@ -1111,7 +1120,7 @@ __global__ __launch_bounds__(RT_WBLOCK, BOUNCE ? RT_WAVES_PER_SIMD_BOUNCE : (DEN
             tr_e = r.eye; tr_d = r.dir; sh.att = r.att;
             sh.level0 = r.level[0]; sh.level1 = r.level[1]; sh.level2 = r.level[2];
             sh.nlevel = r.nlevel; sh.depth = r.depth;
-            phase = PH_CLOSEST; tl.rays++;
+            phase = PH_CLOSEST; count(N_RAYS);
           } else phase = PH_DONE;
           break;
         }
@@ -1146,7 +1155,7 @@ __global__ __launch_bounds__(RT_WBLOCK, BOUNCE ? RT_WAVES_PER_SIMD_BOUNCE : (DEN
               tr_e = sP; tr_d = l; tr_stop = ldist; phase = PH_SHADOW;
               break;
             }
-            tl.rays++; tl.shadow++;   // the reference casts this ray for every (material, light) pair
+            count(N_RAYS); count(N_SHADOW);   // the reference casts this ray for every (material, light) pair
             if (occluded) { sh.li++; continue; }
           }
           if (L.type == RT_SPOT && !(-rt_dot(l, ld3(L.dir)) > L.cos_half)) { sh.li++; continue; }
@@ -1216,13 +1225,19 @@ __global__ __launch_bounds__(RT_WBLOCK, BOUNCE ? RT_WAVES_PER_SIMD_BOUNCE : (DEN
   // dwords instead of 192 single bytes (each byte store is its own partial write to memory).
   // (Pixels whose rays went through the queues are written again, with their sum, by the resolve kernel.)
   if (!queued) {
-    const uint8_t q[3] = {rt_quantise(sh.color.x), rt_quantise(sh.color.y), rt_quantise(sh.color.z)};
+    uint8_t q[3];
+    if (BOUNCE) { q[0] = rt_quantise(sh.color.x); q[1] = rt_quantise(sh.color.y); q[2] = rt_quantise(sh.color.z); }
+    else {
+      asm volatile("" ::: "memory");
+      const uint32_t packed = my_counts[3 * RT_WBLOCK];   // (0 for a lane without a pixel: the bytes of colour 0)
+      q[0] = (uint8_t)packed; q[1] = (uint8_t)(packed >> 8); q[2] = (uint8_t)(packed >> 16);
+    }
     const Pixel pxe = pixel_of(tid);
     const RowMap rows = LATE_STRUCT(rows);
     const int W = LATE(cam).width, H = LATE(cam).height;
     uint8_t* const rgb = LATE(rgb);
     int wave = tid; asm volatile("" : "+v"(wave)); wave >>= 6;
-    if (pxe.valid) tl.rays++;   // the primary ray
+    if (pxe.valid) count(N_RAYS);   // the primary ray
     const int col0 = pxe.col & ~7, lrow0 = pxe.lrow & ~7;   // tile origin (wave-uniform)
     const int last_row = rows.row0 + ((lrow0 + 7) / rows.band_rows) * rows.band_stride + (lrow0 + 7) % rows.band_rows;
     const bool whole = !rows.small && (W & 3) == 0 && col0 + 8 <= W && lrow0 + 8 <= rows.n_local && last_row < H &&
@@ -1255,7 +1270,8 @@ __global__ __launch_bounds__(RT_WBLOCK, BOUNCE ? RT_WAVES_PER_SIMD_BOUNCE : (DEN
   // work counters: wave reduction, one atomic per wave and counter
   if (!LATE(tally)) return;   // nobody asked for statistics
   unsigned long long* const counters = counters_ptr();
-  const uint32_t vals[7] = {tl.rays, tl.shadow, tl.node, tl.leaf, tl.tri, tl.sph, tl.traced};
+  asm volatile("" ::: "memory");
+  const uint32_t vals[7] = {my_counts[0], my_counts[RT_WBLOCK], tl.node, tl.leaf, tl.tri, tl.sph, my_counts[2 * RT_WBLOCK]};
   const int slot[7] = {C_RAYS, C_SHADOW, C_NODE, C_LEAF, C_TRI, C_SPH, C_TRACED};
   for (int k = 0; k < 7; k++) {
     if (!COUNT && k >= 2 && k <= 5) continue;
