@@ -69,6 +69,14 @@ __device__ __forceinline__ float wave_min(float v) {
   return __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, fminf(fminf(r0, r1), fminf(r2, r3)))));
 }
 
+// Index of the lane within its wave, derived on the spot (the compiler may not keep the result of a volatile statement
+// for a later use, which is the point: see render_wave).
+__device__ __forceinline__ int fresh_lane_id() {
+  int t;
+  asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(t));
+  return t;
+}
+
 // Is this lane in the wave-uniform set `mask`?  (The mask becomes the lane predicate directly; a shift by the lane number
 // would keep a 64-bit per-lane value alive wherever it is used.)
 __device__ __forceinline__ bool in_mask(uint64_t mask) { return __builtin_amdgcn_inverse_ballot_w64(mask); }
@@ -78,9 +86,12 @@ __device__ __forceinline__ bool in_mask(uint64_t mask) { return __builtin_amdgcn
 // as one block of assembly - see the call in trace_wave for what the block does and which registers it owns.
 // `nodes` is that variant's array; the root's children start at record top_first, `rem` names the ones to test.
 // Returns the lanes that are still looking for a hit afterwards (shadow rays leave when they are known to be blocked).
+// bary_lds != nullptr: the barycentrics of an accepted triangle go to LDS (word 0 and word RT_WBLOCK of the lane's column
+// there) instead of into `hit` - they change a few times per walk and are read once per closest hit, and as part of `hit`
+// they would be carried through the whole walk in two registers.
 __device__ __forceinline__ uint64_t walk_asm(const float4* nodes, uint32_t variant, uint32_t zpat, const float4* tri_leaf, uint32_t top_first, uint32_t rem,
                                              uint64_t live, const RtVec3& e, const RtVec3& d, const RtVec3& inv, const RtVec3& fc, float neg_eb,
-                                             float stop_t, Hit& hit, WaveStack& st, int lane) {
+                                             float stop_t, Hit& hit, WaveStack& st, float* bary_lds) {
   const RtVec3 c2 = {-d.x, -d.y, -d.z};                   // third column of the triangle solve (triangle.cu:118-120)
   const v2f e_xy = {e.x, e.y}, c_zx = {c2.z, c2.x}, c_yz = {c2.y, c2.z}, c_yx = {c2.y, c2.x};
   uint64_t a_blk = (uint64_t)(uintptr_t)(nodes + 2 * (size_t)top_first);
@@ -132,8 +143,14 @@ __device__ __forceinline__ uint64_t walk_asm(const float4* nodes, uint32_t varia
     } else if (in_mask(a_pass)) {   // the reference's quotients decide (triangle.cu:131-137)
       RtTriNum n;
       n.det = a_det; n.nb = a_nb; n.ng = a_ng; n.nt = a_nt;
-      float t, bet, gam;
-      if (rt_triangle_finish(n, hit.t, t, bet, gam)) { hit.t = t; hit.prim = (int32_t)a_prim; hit.bet = bet; hit.gam = gam; }
+      float t = 0.f, bet = 0.f, gam = 0.f;
+      const bool ok = rt_triangle_finish(n, hit.t, t, bet, gam);
+      asm volatile("" : "+v"(t), "+v"(bet), "+v"(gam));   // (three values known here, used below: not a merge of two paths, which would go through scratch memory)
+      if (ok) {
+        hit.t = t; hit.prim = (int32_t)a_prim;
+        if (bary_lds) { float* const mine = bary_lds + fresh_lane_id(); mine[0] = bet; mine[RT_WBLOCK] = gam; }
+        else { hit.bet = bet; hit.gam = gam; }
+      }
     }
   }
   return a_live;
@@ -271,7 +288,7 @@ __device__ __forceinline__ void trace_wave(const float4* __restrict__ nodes, int
     // closest hit so far, shadow-ray length), v[60:63] the wave's stack, v32 v33 v35 v36 determinant and numerators
     // of a candidate, v34 v37:v39 v64:v79 scratch.
     if ((presorted || zpat != 0u) && FUSED && (rem & 0xffu) != 0u) {
-      live = walk_asm(nodes, variant, zpat, tri_leaf, top_first, rem, live, e, d, inv, fc, neg_eb, stop_t, hit, st, lane);
+      live = walk_asm(nodes, variant, zpat, tri_leaf, top_first, rem, live, e, d, inv, fc, neg_eb, stop_t, hit, st, nullptr);
       if (!live) return;
     } else {
 #endif
@@ -714,12 +731,13 @@ __device__ __forceinline__ void trace_wave(const float4* __restrict__ nodes, int
 // wave whose rays do not (the tiles on the picture's centre lines, a few shadow waves) only the class of the first
 // pending lane is traced.  Returns the lanes that were traced; the others keep their rays for the caller's next round.
 // A lane's result never depends on which other lanes walk with it, so the hits are those of any other grouping.
+// The barycentrics of a triangle hit are left in LDS (see walk_asm), not in `hit`.
 // A direction component so small that its inverse overflows (or a NaN) cannot feed the fused plane distances: such a
 // lane walks with a NaN inverse direction, which the conservative classification can decide nothing about - every node
 // test of the lane goes to the exact test, which does not use the inverse.
 __device__ __forceinline__ uint64_t trace_class(const float4* __restrict__ nodes, int n_wnodes, const float4* __restrict__ tri_leaf,
                                                 const RtSphere* __restrict__ spheres, int n_spheres, bool has_oct, bool want,
-                                                const RtVec3& e, const RtVec3& d, float stop_t, Hit& hit, WaveStack& st, int lane) {
+                                                const RtVec3& e, const RtVec3& d, float stop_t, Hit& hit, WaveStack& st, float* bary_lds) {
   const uint64_t pending = __builtin_amdgcn_ballot_w64(want);
   if (!pending) return 0ull;
   uint64_t cls = pending, after = pending;
@@ -748,7 +766,7 @@ __device__ __forceinline__ uint64_t trace_class(const float4* __restrict__ nodes
         const f4 ra = *(cnode_ptr)(uintptr_t)vnodes, rb = *((cnode_ptr)(uintptr_t)vnodes + 1);
         neg_eb = -rt_slab_margin_bound_fused(ra.x, ra.y, ra.z, ra.w, rb.x, rb.y, e, inv, fu, hit.t);
       }
-      after = walk_asm(vnodes, variant, zpat, tri_leaf, top_first, rem, cls, e, d, inv, fu.c, neg_eb, stop_t, hit, st, lane);
+      after = walk_asm(vnodes, variant, zpat, tri_leaf, top_first, rem, cls, e, d, inv, fu.c, neg_eb, stop_t, hit, st, bary_lds);
     }
   }
   if (n_spheres > 0 && after) {
@@ -870,20 +888,30 @@ __global__ __launch_bounds__(RT_WBLOCK, BOUNCE ? RT_WAVES_PER_SIMD_BOUNCE : (DEN
   const RtSphere* __restrict__ spheres = A.spheres;
   const int n_spheres = A.n_spheres, has_oct = A.has_oct, n_wnodes = A.n_wnodes;
   auto counters_ptr = [&]() { return LATE(counters_all) + ((blockIdx.x + blockIdx.y) & (RT_COUNTER_COPIES - 1)) * RT_COUNTER_STRIDE; };
-  // LDS of a workgroup: the parked shading state, the lane's three ray counters and its finished colour; the packing area
-  // of the epilogue lies over the first word of the state (nothing is parked any more then).  23 words per lane = 5 888 B
+  // LDS of a workgroup: the parked shading state, the lane's three ray counters, its finished colour and the barycentrics of its hit; the packing area
+  // of the epilogue lies over the first word of the state (nothing is parked any more then).  25 words per lane = 6 400 B
   // per wave (without bounce rays) leaves room for 24 waves per compute unit (six per SIMD) in the 160 KB.
   // The counters and the finished colour only ever live there: they are touched a few times per pixel, and as values that
   // every round of the main loop carries along they cost six registers (in the six-wave variant: six spill stores per
   // round) for nothing.
-  __shared__ float parked[(ShadeState<BOUNCE>::WORDS + 4) * RT_WBLOCK];
+  __shared__ float parked[(ShadeState<BOUNCE>::WORDS + 6) * RT_WBLOCK];
   uint32_t (*pack)[48] = (uint32_t (*)[48])parked;   // [wave][48]
-  const int tid = threadIdx.x, lane = tid & 63;
-  float* my_park = &parked[tid];
-  uint32_t* const my_counts = (uint32_t*)my_park + ShadeState<BOUNCE>::WORDS * RT_WBLOCK;   // rays, shadow rays, rays traced, finished colour
-  my_counts[0] = 0u; my_counts[RT_WBLOCK] = 0u; my_counts[2 * RT_WBLOCK] = 0u; my_counts[3 * RT_WBLOCK] = 0u;
+  // The thread's index within its workgroup.  It is handed over in a register at the start and cannot be asked for again;
+  // a workgroup of one wave derives it anew wherever it is needed (two instructions) instead of keeping it - and what is
+  // derived from it, the thread's LDS addresses - alive across the walk.
+#if RT_WBLOCK == 64
+#define TID() fresh_lane_id()
+#define LANE() fresh_lane_id()
+#else
+  const int tid_kept = threadIdx.x;
+#define TID() tid_kept
+#define LANE() (tid_kept & 63)
+#endif
+#define MY_PARK() (&parked[TID()])
+#define MY_COUNTS() ((uint32_t*)MY_PARK() + ShadeState<BOUNCE>::WORDS * RT_WBLOCK)   /* rays, shadow rays, rays traced, finished colour */
+  MY_COUNTS()[0] = 0u; MY_COUNTS()[RT_WBLOCK] = 0u; MY_COUNTS()[2 * RT_WBLOCK] = 0u; MY_COUNTS()[3 * RT_WBLOCK] = 0u;
   enum { N_RAYS = 0, N_SHADOW = 1, N_TRACED = 2 };
-  auto count = [&](int which) { __hip_atomic_fetch_add(my_counts + which * RT_WBLOCK, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); };
+  auto count = [&](int which) { __hip_atomic_fetch_add(MY_COUNTS() + which * RT_WBLOCK, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); };
   __shared__ float cull_sh[16 * (RT_WBLOCK / 64)];   // bounds of the wave's rays during a walk (trace_wave)
   WaveStack st = {0u, 0u, 0u, 0u};
   // Pixel of a thread: wave w of the block owns the 8x8 tile (w % RT_WAVES_X, w / RT_WAVES_X) of the block's pixels.  The
@@ -956,7 +984,7 @@ __global__ __launch_bounds__(RT_WBLOCK, BOUNCE ? RT_WAVES_PER_SIMD_BOUNCE : (DEN
 #endif
   const bool queued = BOUNCE && QUEUES && A.wf.in != nullptr;   // this launch renders a queue of bounce rays, one per lane
   if (!queued) {
-    const Pixel px0 = pixel_of(tid);
+    const Pixel px0 = pixel_of(TID());
     phase = px0.valid ? PH_CLOSEST : PH_DONE;
     const int W = A.cam.width, H = A.cam.height;
     const int i = px0.col, j = H - 1 - px0.row;   // camera.cu:94,118: j counts from the bottom
@@ -989,7 +1017,7 @@ __global__ __launch_bounds__(RT_WBLOCK, BOUNCE ? RT_WAVES_PER_SIMD_BOUNCE : (DEN
       const uint64_t m = __builtin_amdgcn_ballot_w64(true);
       const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
       if (!queued && q_pushes == 0) {   // a primary ray's first push: its pixel gets a block of term slots
-        const Pixel px = pixel_of(tid);
+        const Pixel px = pixel_of(TID());
         const uint64_t mb = __builtin_amdgcn_ballot_w64(true);
         const uint32_t rb = __builtin_amdgcn_mbcnt_hi((uint32_t)(mb >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mb, 0u));
         uint32_t bb = 0u;
@@ -1032,11 +1060,11 @@ __global__ __launch_bounds__(RT_WBLOCK, BOUNCE ? RT_WAVES_PER_SIMD_BOUNCE : (DEN
     n_in = __builtin_amdgcn_readfirstlane(n_in);
     // a short queue: shorter walks in four times as many waves (measured break-even)
     const uint32_t per_wave = n_in < wf.small_below ? 16u : 64u;
-    const uint32_t chunk = blockIdx.x * (RT_WBLOCK / 64) + (uint32_t)(tid >> 6);
+    const uint32_t chunk = blockIdx.x * (RT_WBLOCK / 64) + (uint32_t)(TID() >> 6);
     if ((unsigned long long)chunk * per_wave >= n_in) return;
-    const uint32_t gid = chunk * per_wave + lane;
+    const uint32_t gid = chunk * per_wave + LANE();
     phase = PH_DONE; tr_e = {0.f, 0.f, 0.f}; tr_d = {0.f, 0.f, 1.f};
-    if ((uint32_t)lane < per_wave && gid < n_in) {
+    if ((uint32_t)LANE() < per_wave && gid < n_in) {
       const RtQRay& q = wf.in[(wf.order && n_in >= RT_QUEUE_SORT_MIN) ? wf.order[gid] : gid];
       tr_e = ld3(q.e); tr_d = ld3(q.d); sh.att = ld3(q.att);
       sh.level0 = q.level[0]; sh.level1 = q.level[1]; sh.level2 = q.level[2]; sh.nlevel = q.nlevel; sh.depth = q.depth;
@@ -1053,12 +1081,17 @@ __global__ __launch_bounds__(RT_WBLOCK, BOUNCE ? RT_WAVES_PER_SIMD_BOUNCE : (DEN
       const bool want = phase != PH_DONE;
       // the instrumented variant walks shadow rays to the end, as the reference does, so that its test counts match
       const float stop_t = (phase == PH_SHADOW && !COUNT) ? tr_stop : -1.f;
-      park<BOUNCE>(sh, my_park);
+      park<BOUNCE>(sh, MY_PARK());
       asm volatile("" ::: "memory");
-      if (CLASSES) traced = in_mask(trace_class(nodes, n_wnodes, tri_leaf, spheres, n_spheres, has_oct != 0, want, tr_e, tr_d, stop_t, h, st, lane));
-      else trace_wave<COUNT>(nodes, n_wnodes, tri_leaf, spheres, n_spheres, has_oct != 0, want, tr_e, tr_d, stop_t, h, st, lane, tl, cull_sh + 16 * (tid >> 6));
+      if (CLASSES) {
+        float* const bary = parked + (ShadeState<BOUNCE>::WORDS + 4) * RT_WBLOCK + (RT_WBLOCK == 64 ? 0 : (TID() & ~63));   // the wave's columns of the two barycentric words
+        traced = in_mask(trace_class(nodes, n_wnodes, tri_leaf, spheres, n_spheres, has_oct != 0, want, tr_e, tr_d, stop_t, h, st, bary));
+        asm volatile("" ::: "memory");
+        h.bet = bary[LANE()]; h.gam = bary[RT_WBLOCK + LANE()];   // (only meaningful, and only used, when a triangle was hit)
+      }
+      else trace_wave<COUNT>(nodes, n_wnodes, tri_leaf, spheres, n_spheres, has_oct != 0, want, tr_e, tr_d, stop_t, h, st, LANE(), tl, cull_sh + 16 * (TID() >> 6));
       asm volatile("" ::: "memory");
-      unpark<BOUNCE>(sh, my_park);
+      unpark<BOUNCE>(sh, MY_PARK());
     }
     if (traced) count(N_TRACED);
     const rt_kernarg_ptr ka = late_args();   // one opaque copy for the whole shading phase: its loads go out together
@@ -1068,7 +1101,7 @@ __global__ __launch_bounds__(RT_WBLOCK, BOUNCE ? RT_WAVES_PER_SIMD_BOUNCE : (DEN
         primary = false;
         int32_t* const ids = LATE_AT(ka, ids); float* const ts = LATE_AT(ka, ts);
         if (ids || ts) {
-          const Pixel px = pixel_of(tid);
+          const Pixel px = pixel_of(TID());
           const size_t p = (size_t)px.orow * LATE(cam).width + px.col;
           if (ids) ids[p] = h.prim;
 #ifndef RT_WAVE_TIMES
@@ -1108,7 +1141,7 @@ __global__ __launch_bounds__(RT_WBLOCK, BOUNCE ? RT_WAVES_PER_SIMD_BOUNCE : (DEN
           }
           if (!BOUNCE) {   // the pixel's only ray: its bytes wait in LDS for the end of the wave
             const float cx = 0.f + sh.att.x * sh.colr.x, cy = 0.f + sh.att.y * sh.colr.y, cz = 0.f + sh.att.z * sh.colr.z;
-            my_counts[3 * RT_WBLOCK] = (uint32_t)rt_quantise(cx) | ((uint32_t)rt_quantise(cy) << 8) | ((uint32_t)rt_quantise(cz) << 16);
+            MY_COUNTS()[3 * RT_WBLOCK] = (uint32_t)rt_quantise(cx) | ((uint32_t)rt_quantise(cy) << 8) | ((uint32_t)rt_quantise(cz) << 16);
             phase = PH_DONE;
             break;
           }
@@ -1229,14 +1262,14 @@ __global__ __launch_bounds__(RT_WBLOCK, BOUNCE ? RT_WAVES_PER_SIMD_BOUNCE : (DEN
     if (BOUNCE) { q[0] = rt_quantise(sh.color.x); q[1] = rt_quantise(sh.color.y); q[2] = rt_quantise(sh.color.z); }
     else {
       asm volatile("" ::: "memory");
-      const uint32_t packed = my_counts[3 * RT_WBLOCK];   // (0 for a lane without a pixel: the bytes of colour 0)
+      const uint32_t packed = MY_COUNTS()[3 * RT_WBLOCK];   // (0 for a lane without a pixel: the bytes of colour 0)
       q[0] = (uint8_t)packed; q[1] = (uint8_t)(packed >> 8); q[2] = (uint8_t)(packed >> 16);
     }
-    const Pixel pxe = pixel_of(tid);
+    const Pixel pxe = pixel_of(TID());
     const RowMap rows = LATE_STRUCT(rows);
     const int W = LATE(cam).width, H = LATE(cam).height;
     uint8_t* const rgb = LATE(rgb);
-    int wave = tid; asm volatile("" : "+v"(wave)); wave >>= 6;
+    int wave = TID(); asm volatile("" : "+v"(wave)); wave >>= 6;
     if (pxe.valid) count(N_RAYS);   // the primary ray
     const int col0 = pxe.col & ~7, lrow0 = pxe.lrow & ~7;   // tile origin (wave-uniform)
     const int last_row = rows.row0 + ((lrow0 + 7) / rows.band_rows) * rows.band_stride + (lrow0 + 7) % rows.band_rows;
@@ -1244,10 +1277,10 @@ __global__ __launch_bounds__(RT_WBLOCK, BOUNCE ? RT_WAVES_PER_SIMD_BOUNCE : (DEN
                        (lrow0 / rows.band_rows) == ((lrow0 + 7) / rows.band_rows);   // wave-uniform
     if (whole) {
       uint8_t* pk = (uint8_t*)pack[wave];
-      pk[lane * 3 + 0] = q[0]; pk[lane * 3 + 1] = q[1]; pk[lane * 3 + 2] = q[2];
+      pk[LANE() * 3 + 0] = q[0]; pk[LANE() * 3 + 1] = q[1]; pk[LANE() * 3 + 2] = q[2];
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-      if (lane < 48) {
-        const int r = lane / 6, j = lane - 6 * r;
+      if (LANE() < 48) {
+        const int r = LANE() / 6, j = LANE() - 6 * r;
         const int orow0 = rows.compact ? lrow0 : (rows.row0 + (lrow0 / rows.band_rows) * rows.band_stride + lrow0 % rows.band_rows);
         uint32_t* dst = (uint32_t*)(rgb + ((size_t)(orow0 + r) * W + col0) * 3) + j;
         *dst = pack[wave][r * 6 + j];
@@ -1259,10 +1292,10 @@ __global__ __launch_bounds__(RT_WBLOCK, BOUNCE ? RT_WAVES_PER_SIMD_BOUNCE : (DEN
   }
 #ifdef RT_WAVE_TIMES
   float* const ts = LATE(ts);
-  if (ts && !queued && lane == 0) {
+  if (ts && !queued && LANE() == 0) {
     const unsigned long long wt_end = __builtin_amdgcn_s_memrealtime();
     const uint32_t hw = __builtin_amdgcn_s_getreg((31 << 11) | (0 << 6) | 4), xcc = __builtin_amdgcn_s_getreg((31 << 11) | (0 << 6) | 20);
-    uint32_t* o = (uint32_t*)ts + 4 * (size_t)((tile_of().y * LATE(tiles_x) + tile_of().x) * (RT_WBLOCK / 64) + (tid >> 6));
+    uint32_t* o = (uint32_t*)ts + 4 * (size_t)((tile_of().y * LATE(tiles_x) + tile_of().x) * (RT_WBLOCK / 64) + (TID() >> 6));
     o[0] = (uint32_t)wt_start; o[1] = (uint32_t)wt_end; o[2] = hw; o[3] = xcc;
   }
 #endif
@@ -1271,16 +1304,21 @@ __global__ __launch_bounds__(RT_WBLOCK, BOUNCE ? RT_WAVES_PER_SIMD_BOUNCE : (DEN
   if (!LATE(tally)) return;   // nobody asked for statistics
   unsigned long long* const counters = counters_ptr();
   asm volatile("" ::: "memory");
-  const uint32_t vals[7] = {my_counts[0], my_counts[RT_WBLOCK], tl.node, tl.leaf, tl.tri, tl.sph, my_counts[2 * RT_WBLOCK]};
+  const uint32_t vals[7] = {MY_COUNTS()[0], MY_COUNTS()[RT_WBLOCK], tl.node, tl.leaf, tl.tri, tl.sph, MY_COUNTS()[2 * RT_WBLOCK]};
   const int slot[7] = {C_RAYS, C_SHADOW, C_NODE, C_LEAF, C_TRI, C_SPH, C_TRACED};
   for (int k = 0; k < 7; k++) {
     if (!COUNT && k >= 2 && k <= 5) continue;
     uint32_t v = vals[k];
     for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
-    if (lane == 0 && v) atomicAdd(&counters[slot[k]], (unsigned long long)v);
+    if (LANE() == 0 && v) atomicAdd(&counters[slot[k]], (unsigned long long)v);
   }
-  if ((COUNT || RT_PATHS_ON) && lane == 0) for (int k = 0; k < 8; k++) if (tl.w[k]) atomicAdd(&counters[C_W_TRACE + k], (unsigned long long)tl.w[k]);
+  if ((COUNT || RT_PATHS_ON) && LANE() == 0) for (int k = 0; k < 8; k++) if (tl.w[k]) atomicAdd(&counters[C_W_TRACE + k], (unsigned long long)tl.w[k]);
 }
+
+#undef TID
+#undef LANE
+#undef MY_PARK
+#undef MY_COUNTS
 
 }  // namespace
 
