@@ -34,7 +34,8 @@ def main():
         for r in csv.DictReader(open(stats[0])):
             if "render_wave" in r["Name"]:
                 avg_ns, calls = float(r["AverageNs"]), int(r["Calls"])
-                kernel = r["Name"].split("(")[0]
+                m = re.search(r"render_wave<[^>]*>", r["Name"])
+                kernel = m.group(0) if m else r["Name"]
                 break
     base = os.path.join(ROOT, "profiles", "r%s_%s" % (rnd, tag))
     with open(base + "_pmc.txt", "w") as f:
