@@ -125,7 +125,8 @@ int rt_dscene_fork(const rt_dscene* d, rt_dscene** out);
  *   stream: hipStream_t (NULL = default stream).  The call is asynchronous
  *           unless RT_RENDER_TIME is set, `stats` is non-NULL (stats are
  *           read back, which synchronises the stream) or the scene's bounce
- *           rays go through queues (RT_RENDER_QUEUED; queue fills are read back).
+ *           rays go through queues (glass meshes, RT_RENDER_QUEUED: one read-back at the end of the frame tells
+ *           whether a queue overflowed; the frame is then rendered on the stacks instead).
  * An rt_dscene owns one set of counters and queue buffers: calls on the same
  * rt_dscene must not overlap (rt_dscene_fork gives each concurrent stream a handle of its own).
  * Every entry point leaves the calling thread's current HIP device as it found it. */
@@ -134,13 +135,14 @@ int rt_render_rows(rt_dscene* d, int row_begin, int row_end, uint8_t* d_rgb, int
 
 /* rt_render_rows for callers that cannot allocate device memory (code under HIP graph capture, tight serving loops,
  * harnesses that forbid hipMalloc).  It has no counterpart in the reference.  Same arguments, same bytes, but every
- * scratch buffer of the render (work counters; the queues, term lists and sort areas of scenes rendered from queues)
+ * scratch buffer of the render (work counters; the queues, term slots and sort areas of scenes rendered from queues)
  * lives in a 64 MiB array inside the library's code object instead of memory the rt_dscene allocates and grows: the
  * call contains no hipMalloc / hipFree and nothing that allocates, and read-backs land in page-locked words set up
  * by rt_scene_upload.  Limits: RT_RENDER_TIME is refused (RT_ERR_ARG; it creates events); a scene rendered from queues
- * (glass meshes, or RT_RENDER_QUEUED) needs about 560 bytes of scratch per pixel of the call, so calls beyond about
- * 119 000 pixels of such a scene are refused with RT_ERR_LIMIT - render fewer rows per call or pass RT_RENDER_STACKED,
- * which needs the counters only; every other scene is accepted at any size.  Each GPU has ONE such array, shared by all
+ * (glass meshes, or RT_RENDER_QUEUED) needs 8 MiB of sort bins plus, at depth 3, about 516 bytes of scratch per pixel
+ * of the call (more at greater depths: one 16-byte term slot per node of a pixel's ray tree), so calls beyond about
+ * 113 000 pixels of such a scene are refused with RT_ERR_LIMIT - render fewer rows per call or pass
+ * RT_RENDER_STACKED, which needs the counters only; every other scene is accepted at any size.  Each GPU has ONE such array, shared by all
  * rt_dscene handles of the process: calls that overlap on one GPU race on it (the counters and queue fills are cleared
  * by each call that uses them, so calls in sequence are independent).  Without `stats`, and for scenes not rendered
  * from queues, the call only enqueues kernels and memsets on `stream`. */
