@@ -56,7 +56,8 @@ class SceneInfo(C.Structure):
 class Stats(C.Structure):
     _fields_ = [(n, C.c_uint64) for n in (
         "rays", "shadow_rays", "node_tests", "leaf_visits", "tri_tests", "sphere_tests", "ub_leave_level0",
-        "ub_level_overflow", "ub_stack_overflow", "rays_traced")] + [("wave_paths", C.c_uint64 * 8), ("kernel_ms", C.c_float), ("copy_ms", C.c_float)]
+        "ub_level_overflow", "ub_stack_overflow", "rays_traced")] + [("wave_paths", C.c_uint64 * 8), ("kernel_ms", C.c_float), ("copy_ms", C.c_float),
+                                                                    ("from_queues", C.c_uint32), ("queue_fallback", C.c_uint32)]
 
     def as_dict(self):
         d = {n: getattr(self, n) for n, _ in self._fields_ if n != "wave_paths"}

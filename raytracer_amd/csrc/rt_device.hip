@@ -270,14 +270,16 @@ int prepare_wavefront(const SceneArrays& S, RenderCtx& ctx, const RowMap& rows, 
   if (p < 1 || D < 1 || (D - 1) * (p - 1) + p > RT_RAY_STACK || n_out > 0xffffffffull) return RT_OK;
   const uint32_t slots = tree_slots(D, p);
   if (slots > RT_TERM_SLOTS_MAX) return RT_OK;
-  const unsigned long long n_px = (unsigned long long)S.view.cam.width * rows.n_local;
+  unsigned long long n_px = (unsigned long long)S.view.cam.width * rows.n_local;
+  // (tests: capacities as if the call had this many pixels, so that the queues overflow and the frame falls back to the stacks)
+  if (const char* cap = getenv("RT_AMD_QUEUE_CAP_PIXELS")) n_px = std::min<unsigned long long>(n_px, strtoull(cap, nullptr, 10));
   // a fixed arena is cut to what the call needs; one that may grow keeps a floor so that small frames do not make it grow step by step
-  const unsigned long long floor_n = ctx.arena.fixed ? 64ull : (1ull << 16);
+  const unsigned long long floor_n = (ctx.arena.fixed || getenv("RT_AMD_QUEUE_CAP_PIXELS")) ? 64ull : (1ull << 16);
   const unsigned long long want_q = std::max<unsigned long long>(floor_n, 2 * n_px);
   unsigned long long want_b = std::max<unsigned long long>(floor_n, n_px);
   if (!ctx.arena.fixed) want_b = std::min<unsigned long long>(want_b, RT_TERM_POOL_MAX_BYTES / ((unsigned long long)slots * sizeof(RtTermRGB)));
   if (want_q > 0xffffffffull / 2 || want_b > 0xffffffffull / 2) return RT_OK;
-  if (!ctx.wf_laid_out || ctx.wf_layout.queue_cap < want_q || ctx.wf_layout.block_cap < want_b || ctx.wf_layout.slots != slots || ctx.arena.fixed) {
+  if (!ctx.wf_laid_out || ctx.wf_layout.queue_cap < want_q || ctx.wf_layout.block_cap < want_b || ctx.wf_layout.slots != slots || ctx.arena.fixed || getenv("RT_AMD_QUEUE_CAP_PIXELS")) {
     WavefrontLayout L;
     wavefront_layout((uint32_t)want_q, (uint32_t)want_b, slots, &L);
     if (ctx.arena.bytes < L.total) {
@@ -380,6 +382,7 @@ int launch_render(const SceneArrays& S, RenderCtx& ctx, RowMap rows, uint8_t* d_
   unsigned long long* const d_counters = (unsigned long long*)ctx.arena.base;
   // the counters are only read back for a caller that passes an rt_stats: no need to clear them for anybody else
   if (stats) HIP_TRY(hipMemsetAsync(d_counters, 0, RT_COUNTER_BYTES, stream));
+  bool used_queues = false, fell_back = false;
   EventPair ev;
   const bool timed = (flags & RT_RENDER_TIME) != 0;
   if (timed) { HIP_TRY(hipEventCreate(&ev.a)); HIP_TRY(hipEventCreate(&ev.b)); HIP_TRY(hipEventRecord(ev.a, stream)); }
@@ -407,6 +410,7 @@ int launch_render(const SceneArrays& S, RenderCtx& ctx, RowMap rows, uint8_t* d_
         if (rc != RT_OK) return rc;
         // a frame that has to be rendered again must not be counted twice
         if (!done && stats) HIP_TRY(hipMemsetAsync(d_counters, 0, RT_COUNTER_BYTES, stream));
+        used_queues = done; fell_back = !done;
       }
       if (!done) {
         RtQueues none; memset(&none, 0, sizeof none);
@@ -433,6 +437,7 @@ int launch_render(const SceneArrays& S, RenderCtx& ctx, RowMap rows, uint8_t* d_
     stats->ub_level_overflow = h[C_UB_OVER]; stats->ub_stack_overflow = h[C_UB_STACK];
     stats->rays_traced = (flags & RT_RENDER_LITERAL) ? h[C_RAYS] : h[C_TRACED]; stats->kernel_ms = ms;
     for (int k = 0; k < 8; k++) stats->wave_paths[k] = h[C_W_TRACE + k];
+    stats->from_queues = used_queues ? 1u : 0u; stats->queue_fallback = fell_back ? 1u : 0u;
   }
   return RT_OK;
 }

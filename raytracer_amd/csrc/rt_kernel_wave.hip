@@ -557,7 +557,9 @@ __device__ __forceinline__ void trace_wave(const float4* __restrict__ nodes, int
         }
       }
       if (und_m) {
+#ifndef RT_PATH_HIST
         if (PATHS) tl.w[2]++;
+#endif
         // Rare path (about 1 % of the node tests): the per-ray constants of the exact test are derived here, from
         // values the compiler cannot hoist, instead of occupying registers across the whole walk.
         RtVec3 dd = d, ee = e; float T = hit.t;
@@ -628,6 +630,11 @@ __device__ __forceinline__ void trace_wave(const float4* __restrict__ nodes, int
       // leaf: every triangle in insertion order (octtree.cu:264-274); all lanes in acc_m test the same triangle
       if (COUNT && ((acc_m >> lane) & 1ull)) { tl.leaf++; tl.tri += (uint32_t)count; }
       if (count == 0) continue;
+#ifdef RT_PATH_HIST
+      // measurement build: triangle iterations by how many lanes of the wave take part (w[5]: one lane, w[6]: 2-4, w[7]: 5-16;
+      // the stage counters are not kept then)
+      if (PATHS) { const int pc = __builtin_popcountll(acc_m); tl.w[pc == 1 ? 5 : (pc <= 4 ? 6 : (pc <= 16 ? 7 : 2))] += (uint32_t)count; }
+#endif
       uint64_t changed_m = 0ull;
       // One triangle: the record is in SGPRs (q0..q3 as laid out in RtTriLeaf), every lane of acc_m tests it.
       auto test_triangle = [&](const float4& q0, const float4& q1, const float4& q2, const float4& q3) {
@@ -653,7 +660,9 @@ __device__ __forceinline__ void trace_wave(const float4* __restrict__ nodes, int
         // 0 <= beta <= 1  <=>  0 <= nbs <= |det|   (det == 0 cannot survive stage 3: 0 < nts <= 0)
         uint64_t pass_m = __builtin_amdgcn_ballot_w64(nbs >= 0.f) & __builtin_amdgcn_ballot_w64(nbs <= ad) & acc_m;
         if (!pass_m) return;
+#ifndef RT_PATH_HIST
         if (PATHS) tl.w[5]++;
+#endif
         const RtVec3 e1 = {q1.x, q1.y, q1.z}, e2 = {q2.x, q2.y, q2.w};
         const RtVec3 b = {bxy.x, bxy.y, bz};
         // stage 2: gamma numerator
@@ -664,7 +673,9 @@ __device__ __forceinline__ void trace_wave(const float4* __restrict__ nodes, int
         const float ngs = rt_from_bits(rt_bits(n.ng) ^ s);
         pass_m &= __builtin_amdgcn_ballot_w64(ngs >= 0.f) & __builtin_amdgcn_ballot_w64(ngs <= ad);
         if (!pass_m) return;
+#ifndef RT_PATH_HIST
         if (PATHS) tl.w[6]++;
+#endif
         // stage 3: t numerator; t > 0, and t clearly beyond the closest hit is rejected without dividing
         const float m02 = e1.y * e2.z - e1.z * e2.y;
         const float m12 = -e1.x * e2.z + e1.z * e2.x;
@@ -673,7 +684,9 @@ __device__ __forceinline__ void trace_wave(const float4* __restrict__ nodes, int
         const float nts = rt_from_bits(rt_bits(n.nt) ^ s);
         pass_m &= __builtin_amdgcn_ballot_w64(nts > 0.f) & __builtin_amdgcn_ballot_w64(nts <= (hit.t * ad) * 1.000001f);
         if (!pass_m) return;
+#ifndef RT_PATH_HIST
         if (PATHS) tl.w[7]++;
+#endif
         if ((pass_m >> lane) & 1ull) {   // the reference's quotients decide (triangle.cu:131-137)
           float t, bet, gam;
           if (rt_triangle_finish(n, hit.t, t, bet, gam)) { hit.t = t; hit.prim = (int32_t)__float_as_uint(q0.w); hit.bet = bet; hit.gam = gam; }

@@ -444,3 +444,34 @@ def test_against_committed_golden_fixtures(name):
     assert np.array_equal(oids, g["ids"]) and np.array_equal(ots.view(np.uint32), g["t_bits"]), "the oracle built here left its fixture"
     o_ok, o_diff, o_max = _rgb_close(orgb, g["rgb"])
     assert o_ok >= 0.999, ("oracle vs fixture", name, o_diff, o_max)
+
+
+@pytest.mark.parametrize("w,h", [(1920, 1080), (3840, 2160)])
+def test_glass_bunny_full_size_both_ways(w, h):
+    # the configuration rendered from queues, at the sizes it is measured at: bounce rays generation by generation from
+    # queues and on the lanes' stacks give the same bytes and the same ray counts (a property; the oracle takes minutes here)
+    ds = rt.DeviceScene(rt.Scene("scenes/meshTransparentBunny.json", w, h, 3))
+    a, ida, _, sa = ds.render_host(flags=rt.RT_RENDER_QUEUED)
+    b, idb, _, sb = ds.render_host(flags=rt.RT_RENDER_STACKED)
+    c, _, _, sc = ds.render_host(want_ids=False)           # the library's own choice (queues)
+    assert np.array_equal(a, b) and np.array_equal(a, c) and np.array_equal(ida, idb)
+    for k in ("rays", "shadow_rays", "rays_traced", "ub_leave_level0", "ub_level_overflow", "ub_stack_overflow"):
+        assert sa[k] == sb[k] == sc[k], (k, sa[k], sb[k], sc[k])
+    assert sa["rays"] > w * h and sa["from_queues"] == 1 and sc["from_queues"] == 1 and sb["from_queues"] == 0
+
+
+def test_queue_overflow_falls_back_to_the_stacks(monkeypatch):
+    # queues and block pool sized as for a 64-pixel call: they overflow at once, the frame is rendered on the stacks
+    # instead, and nothing of the abandoned attempt shows (bytes and counts of the stacked way)
+    ds = rt.DeviceScene(rt.Scene("scenes/meshTransparentBunny.json", 256, 256, 3))
+    want, _, _, sw = ds.render_host(want_ids=False, flags=rt.RT_RENDER_STACKED)
+    monkeypatch.setenv("RT_AMD_QUEUE_CAP_PIXELS", "64")
+    got, _, _, sg = ds.render_host(want_ids=False, flags=rt.RT_RENDER_QUEUED)
+    monkeypatch.delenv("RT_AMD_QUEUE_CAP_PIXELS")
+    again, _, _, sa = ds.render_host(want_ids=False, flags=rt.RT_RENDER_QUEUED)      # and with room again: from queues
+    assert np.array_equal(got, want) and np.array_equal(again, want)
+    assert (sw["from_queues"], sw["queue_fallback"]) == (0, 0) and (sg["from_queues"], sg["queue_fallback"]) == (0, 1)
+    assert (sa["from_queues"], sa["queue_fallback"]) == (1, 0)
+    for k in ("rays", "shadow_rays", "rays_traced"):
+        assert sg[k] == sw[k] == sa[k], (k, sg[k], sw[k], sa[k])
+
