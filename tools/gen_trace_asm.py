@@ -296,10 +296,10 @@ def triangle(q, other, tag, next_off):
          "v_add_f32 v78, v78, v79",
          "v_mul_f32 v79, v75, %s" % bz,                                                         # m20 b.z
          "v_add_f32 %s, v78, v79" % nb,
-         "v_bitop3_b32 %s, %s, %s, %s bitop3:0x6c" % (nbs, det, nb, SIGN),                     # nb with the determinant's sign folded in
-         "v_cmp_le_f32 vcc, 0, %s" % nbs,
-         "v_cmp_ge_f32_e64 %s, |%s|, %s" % (PASS, det, nbs),
-         "s_and_b64 %s, %s, vcc" % (PASS, PASS),
+         # 0 <= nb / det <= 1 can only hold when nb lies between 0 and det (either sign): the middle one of (nb, 0, det) is nb itself.
+         # (A filter: it lets det == 0 and zeros of either sign through; the quotients decide.)
+         "v_med3_f32 %s, %s, 0, %s" % (nbs, nb, det),
+         "v_cmp_eq_f32_e64 %s, %s, %s" % (PASS, nbs, nb),
          "s_and_b64 %s, %s, %s" % (PASS, PASS, ACC),
          "s_cbranch_scc0 LT_end%s_%%=" % tag,
          # stage 2: gamma numerator
@@ -317,14 +317,12 @@ def triangle(q, other, tag, next_off):
          "v_add_f32 v37, v37, v38",
          "v_mul_f32 v38, %s, %s" % (sg, bz),
          "v_add_f32 %s, v37, v38" % ng,
-         "v_and_b32 %s, 0x80000000, %s" % (sg, det),
-         "v_xor_b32 v38, %s, %s" % (sg, ng),
-         "v_cmp_le_f32 vcc, 0, v38",
-         "v_cmp_ge_f32_e64 %s, |%s|, v38" % (T64, det),
-         "s_and_b64 %s, %s, vcc" % (T64, T64),
+         "v_med3_f32 v38, %s, 0, %s" % (ng, det),                                                # the same filter for gamma
+         "v_cmp_eq_f32_e64 %s, v38, %s" % (T64, ng),
          "s_and_b64 %s, %s, %s" % (PASS, PASS, T64),
          "s_cbranch_scc0 LT_end%s_%%=" % tag,
          # stage 3: t numerator from the record's e1 x e2; t > 0, and t clearly beyond the closest hit is rejected without dividing
+         "v_and_b32 %s, 0x80000000, %s" % (sg, det),
          "v_mul_f32 v37, %s, %s" % (s(q + 7), bx),
          "v_mul_f32 v38, %s, %s" % (s(q + 14), by),
          "v_add_f32 v37, v37, v38",
