@@ -16,13 +16,15 @@ all: $(LIB) $(RUN) oracle
 
 $(CSRC)/rt_host.o: $(CSRC)/rt_host.cpp $(CSRC)/rt_internal.h include/rt_amd.h
 	$(CXX) $(HOSTFLAGS) -c $< -o $@
+$(CSRC)/rt_image.o: $(CSRC)/rt_image.cpp $(CSRC)/rt_internal.h include/rt_amd.h
+	$(CXX) $(HOSTFLAGS) -c $< -o $@
 
 HIPOBJS := $(CSRC)/rt_device.o $(CSRC)/rt_kernel_lane.o $(CSRC)/rt_kernel_wave.o $(CSRC)/rt_queue.o $(CSRC)/rt_gather.o
 
 $(CSRC)/%.o: $(CSRC)/%.hip $(CSRC)/rt_kernels.h $(CSRC)/rt_internal.h $(CSRC)/rt_math.h $(CSRC)/rt_trace_asm.inc include/rt_amd.h
 	$(HIPCC) $(HIPFLAGS) -c $< -o $@
 
-$(LIB): $(CSRC)/rt_host.o $(HIPOBJS)
+$(LIB): $(CSRC)/rt_host.o $(CSRC)/rt_image.o $(HIPOBJS)
 	$(HIPCC) --offload-arch=$(ARCH) -shared -fPIC -pthread -o $@ $^ -lz -ldl
 
 $(RUN): $(CSRC)/run_main.cpp $(LIB) include/rt_amd.h

@@ -189,6 +189,10 @@ int rt_unpack_bands(const uint8_t* d_gathered, size_t bytes_per_rank, int nranks
  * summed over the devices; kernel_ms = first launch to last tile in place on the first device, copy_ms = the copy out. */
 int rt_render_frame_gathered(rt_dscene* const* scenes, rt_comm* const* comms, int n, int band_rows, uint8_t* h_rgb,
                              unsigned flags, rt_stats* stats);
+/* Decode a texture image (8-bit non-interlaced PNG, baseline JPEG) to RGB8, row 0 on top: the loader behind the
+ * `textures` of resources.json.  The reference's own loader is an unfinished stub (material/material.cu:276-289).
+ * rgb == NULL: only width and height are returned; else `capacity` must be at least width * height * 3. */
+int rt_image_load(const char* path, int* width, int* height, uint8_t* rgb, size_t capacity);
 /* Size, counts and device of an uploaded scene (device may be NULL). */
 int rt_dscene_get_info(const rt_dscene* d, rt_scene_info* out, int* device);
 

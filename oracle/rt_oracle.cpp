@@ -193,10 +193,11 @@ inline void jvec(const JNode& n, std::vector<float>& v) { for (auto& k : n.kids)
 enum MatType { LAMBERT = 0, PHONG = 1, REFLECTIVE = 2, DIELECTRIC = 3 };
 enum LightType { PUNCTUAL = 0, SPOT = 1, AMBIENT = 2, DIRECTIONAL = 3 };
 
-struct Material { int type; float col[3]; float att[3]; float param; };
+struct Material { int type; float col[3]; float att[3]; float param; int tex; bool bilinear, for_ambient; };   // tex >= 0: colour from that texture
+struct Texture { int w, h; std::vector<uint8_t> rgb; };   // RGB8, row 0 on top
 struct Light { int type; float col[3], pos[3], dir[3], angle; };
 struct Sphere { float c[3], r; std::vector<int> mats; };
-struct Tri { float v[3][3]; float n[3][3]; int mesh; };
+struct Tri { float v[3][3]; float n[3][3]; int mesh; float uv[3][2]; };
 
 struct ONode {            // pointer-free restatement of OctNode/OctBranch/OctLeave
   float ini[3], end[3];
@@ -217,6 +218,7 @@ struct Scene {
   std::vector<Sphere> spheres;
   std::vector<Tri> tris;
   std::vector<std::vector<int>> mesh_mats;
+  std::vector<Texture> textures;
   std::vector<ONode> nodes;   // nodes[0] = root when has_oct
   bool has_oct = false;
   std::string error;
@@ -243,7 +245,7 @@ struct LineTok {
 };
 
 struct MeshData {
-  struct V { float p[3]; float n[3]; bool has_n; std::vector<int> adj; };
+  struct V { float p[3]; float n[3]; bool has_n; std::vector<int> adj; float uv[2]; };
   std::map<int, V> verts;                 // keyed by position index, first-seen attributes win
   std::vector<std::array<int, 3>> faces;  // vertex keys
   std::vector<std::array<float, 3>> fn;   // face normals
@@ -296,15 +298,17 @@ bool load_obj(const std::string& path, MeshData& m, std::string& err) {
   while (token == "f") {
     std::array<int, 3> fk;
     for (int i = 0; i < 3; i++) {
-      int vin, nin = -1;
+      int vin, nin = -1, uvin = -1;
       if (n.size()) vin = (int)strtoul(lt.next('/').c_str(), nullptr, 10) - 1;
       else vin = (int)strtoul(lt.next(' ').c_str(), nullptr, 10) - 1;
-      if (uv.size()) (void)lt.next('/');
+      if (uv.size()) uvin = (int)strtoul(lt.next('/').c_str(), nullptr, 10) - 1;
       else if (n.size()) (void)lt.next('/');
       if (n.size()) nin = (int)strtoul(lt.next(' ').c_str(), nullptr, 10) - 1;
       if (vin < 0 || vin >= (int)v.size()) { err = "bad vertex index in " + path; return false; }
       if (m.verts.find(vin) == m.verts.end()) {
         MeshData::V nv; nv.p[0] = v[vin][0]; nv.p[1] = v[vin][1]; nv.p[2] = v[vin][2]; nv.has_n = false;
+        nv.uv[0] = nv.uv[1] = 0.f;
+        if (uvin >= 0 && uvin < (int)uv.size()) { nv.uv[0] = uv[uvin][0]; nv.uv[1] = uv[uvin][1]; }   // parsing.cu:106-107
         if (nin != -1) {
           if (nin < 0 || nin >= (int)n.size()) { err = "bad normal index in " + path; return false; }
           nv.n[0] = n[nin][0]; nv.n[1] = n[nin][1]; nv.n[2] = n[nin][2]; nv.has_n = true;
@@ -415,6 +419,10 @@ struct OctBuilder {
   }
 };
 
+// Texture images are handed to the checker already decoded (oracle_provide_texture: by another decoder than the
+// library's, or by the library's when only the lookup is under test), keyed by the file_path written in the resources.
+static std::map<std::string, Texture> g_provided_textures;
+
 // -------------------------------------------------------------- parsing
 bool load_scene(Scene& sc, const std::string& scene_path, const std::string& res_path, int W, int H, int depth,
                 const std::string& base_dir) {
@@ -422,10 +430,20 @@ bool load_scene(Scene& sc, const std::string& scene_path, const std::string& res
   if (!read_json(res_path, res)) { sc.error = "cannot read " + res_path; return false; }
   if (!read_json(scene_path, world)) { sc.error = "cannot read " + scene_path; return false; }
   std::map<std::string, int> mat_by_name;
+  std::map<std::string, std::string> tex_file;      // texture name -> file_path as written in the resources
+  std::vector<std::string> tex_of;                  // per material: its texture's name, "" = none
   for (auto& rp : res.kids) {                                           // parsing.cu:181-269
+    if (rp.first == "textures") {
+      for (auto& te : rp.second.kids) {
+        std::string name, file;
+        for (auto& tp : te.second.kids) { if (tp.first == "name") name = tp.second.text; else if (tp.first == "file_path") file = tp.second.text; }
+        if (name.size()) tex_file[name] = file;
+      }
+      continue;
+    }
     if (rp.first != "materials") continue;
     for (auto& me : rp.second.kids) {
-      std::vector<float> col, att; std::string type, name; int shin = 0; float ior = 0;
+      std::vector<float> col, att; std::string type, name, texture, filtering; int shin = 0; float ior = 0; bool for_ambient = false;
       for (auto& mp : me.second.kids) {
         if (mp.first == "__type__") type = mp.second.text;
         else if (mp.first == "name") name = mp.second.text;
@@ -434,17 +452,27 @@ bool load_scene(Scene& sc, const std::string& scene_path, const std::string& res
         else if (mp.first == "attenuation") jvec(mp.second, att);
         else if (mp.first == "refraction_index") ior = jf(mp.second);
         else if (mp.first == "brdf") type = mp.second.text;
+        else if (mp.first == "color_texture") texture = mp.second.text;
+        else if (mp.first == "texture_filtering") filtering = mp.second.text;
+        else if (mp.first == "use_for_ambient") for_ambient = mp.second.text == "true";
       }
-      Material m; memset(&m, 0, sizeof m);
+      Material m; memset(&m, 0, sizeof m); m.tex = -1;
       if (type == "lambert") m.type = LAMBERT;
       else if (type == "blinnPhong") { m.type = PHONG; m.param = (float)shin; }
       else if (type == "reflective_material") m.type = REFLECTIVE;
       else if (type == "dielectric_material") { m.type = DIELECTRIC; m.param = ior; }
       else continue;
-      if (col.size() < 3) continue;   // texture-flavoured entries have no colour: the reference reads out of bounds here
+      if (texture.size() && (m.type == LAMBERT || m.type == PHONG)) {
+        // `brdf_color_texture_material`: no behaviour in the reference (its TextureMaterial is a stub, material.cu:263-301).
+        // Defined here, for the checker's sake, exactly as the library defines it: see texture_colour below.
+        m.tex = -2; m.bilinear = filtering == "bilinear"; m.for_ambient = for_ambient;   // (-2: resolved once a scene uses it)
+        mat_by_name[name] = (int)sc.mats.size(); sc.mats.push_back(m); tex_of.push_back(texture);
+        continue;
+      }
+      if (col.size() < 3) continue;   // other entries without a colour: the reference reads out of bounds here
       for (int k = 0; k < 3; k++) m.col[k] = col[k];
       if (m.type == DIELECTRIC) { if (att.size() < 3) continue; for (int k = 0; k < 3; k++) m.att[k] = att[k]; }
-      mat_by_name[name] = (int)sc.mats.size(); sc.mats.push_back(m);
+      mat_by_name[name] = (int)sc.mats.size(); sc.mats.push_back(m); tex_of.push_back("");
     }
   }
   std::vector<float> e, up, target; float fov = 0; bool have_cam = false;
@@ -494,6 +522,7 @@ bool load_scene(Scene& sc, const std::string& scene_path, const std::string& res
             for (int j = 0; j < 3; j++) {
               const MeshData::V& v = md.verts[md.faces[f][j]];
               for (int k = 0; k < 3; k++) { t.v[j][k] = v.p[k]; t.n[j][k] = v.has_n ? v.n[k] : 0.0f; }
+              t.uv[j][0] = v.uv[0]; t.uv[j][1] = v.uv[1];
             }
             sc.tris.push_back(t);
           }
@@ -536,6 +565,26 @@ bool load_scene(Scene& sc, const std::string& scene_path, const std::string& res
       }
     }
   }
+  {   // textures of the materials some object uses
+    std::map<std::string, int> loaded;
+    auto use = [&](int mi) -> bool {
+      if (sc.mats[mi].tex != -2) return true;
+      const std::string& tname = tex_of[mi];
+      auto it = loaded.find(tname);
+      if (it == loaded.end()) {
+        auto tf = tex_file.find(tname);
+        if (tf == tex_file.end()) { sc.error = "unknown texture " + tname; return false; }
+        auto pv = g_provided_textures.find(tf->second);
+        if (pv == g_provided_textures.end()) { sc.error = "texture " + tf->second + " was not provided to the checker"; return false; }
+        it = loaded.emplace(tname, (int)sc.textures.size()).first;
+        sc.textures.push_back(pv->second);
+      }
+      sc.mats[mi].tex = it->second;
+      return true;
+    };
+    for (auto& sp : sc.spheres) for (int mi : sp.mats) if (!use(mi)) return false;
+    for (auto& mm : sc.mesh_mats) for (int mi : mm) if (!use(mi)) return false;
+  }
   if (!have_cam || e.size() < 3 || up.size() < 3 || target.size() < 3) { sc.error = "scene has no camera"; return false; }
   // camera.cu:45-68
   Camera& c = sc.cam;
@@ -568,6 +617,7 @@ bool load_scene(Scene& sc, const std::string& scene_path, const std::string& res
 struct Ray {                    // ray.cuh:9-13
   float eye[3], dir[3], t, ip[3], n[3], col[3], att[3], level[3];
   int sph, tri; bool oct; int depth, nlevel;
+  float uv[2];   // texture coordinates of the hit (texture materials; not in the reference)
 };
 struct RayStack { Ray r[kRayStack]; int size; };
 
@@ -597,6 +647,7 @@ struct Tracer {
           float wv0 = v0[k] * alp, wv1 = v1[k] * bet, wv2 = v2[k] * gam;
           ray.ip[k] = (wv0 + wv1) + wv2;
         }
+        for (int k = 0; k < 2; k++) ray.uv[k] = (t.uv[0][k] * alp + t.uv[1][k] * bet) + t.uv[2][k] * gam;
         ray.tri = id; ray.sph = -1;
       }
       return true;
@@ -643,6 +694,8 @@ struct Tracer {
           for (int k = 0; k < 3; k++) ray.ip[k] = ray.eye[k] + ray.dir[k] * ray.t;
           for (int k = 0; k < 3; k++) ray.n[k] = ray.ip[k] - s.c[k];
           dnormalize(ray.n);
+          ray.uv[0] = 0.5f + atan2f(ray.n[2], ray.n[0]) * 0.15915494f;   // longitude and latitude of the unit normal
+          ray.uv[1] = 0.5f + asinf(ray.n[1] < -1.f ? -1.f : (ray.n[1] > 1.f ? 1.f : ray.n[1])) * 0.31830987f;
           ray.sph = id; ray.tri = -1;
         }
         return true;
@@ -712,8 +765,40 @@ struct Tracer {
     return true;
   }
 
+  // Colour of texture `T` at (u, v): u and v repeat, v = 1 is the top row; nearest texel, or the four texels around
+  // (u W - 0.5, (1 - v) H - 0.5) blended along x, then along y; a channel is its byte / 255.
+  static void texture_colour(const Texture& T, bool bilinear, float u, float v, float* out) {
+    const int W = T.w, H = T.h;
+    auto texel = [&](int x, int y, float* c) { const uint8_t* p = &T.rgb[3 * ((size_t)y * W + x)]; for (int k = 0; k < 3; k++) c[k] = (float)p[k] / 255.f; };
+    if (!(u - u == 0.f) || !(v - v == 0.f)) { u = 0.f; v = 0.f; }
+    u = u - floorf(u); v = v - floorf(v);
+    const float fx = u * (float)W, fy = (1.f - v) * (float)H;
+    if (!bilinear) {
+      int x = (int)fx, y = (int)fy;
+      x = x < W ? x : W - 1; y = y < H ? y : H - 1;
+      texel(x, y, out);
+      return;
+    }
+    const float gx = fx - 0.5f, gy = fy - 0.5f;
+    const float x0f = floorf(gx), y0f = floorf(gy);
+    const float tx = gx - x0f, ty = gy - y0f;
+    int x0 = (int)x0f, y0 = (int)y0f;
+    int x1 = x0 + 1, y1 = y0 + 1;
+    x0 = x0 < 0 ? x0 + W : x0; y0 = y0 < 0 ? y0 + H : y0;
+    x1 = x1 >= W ? x1 - W : x1; y1 = y1 >= H ? y1 - H : y1;
+    x0 = x0 < W ? x0 : W - 1; y0 = y0 < H ? y0 : H - 1;
+    float c00[3], c10[3], c01[3], c11[3];
+    texel(x0, y0, c00); texel(x1, y0, c10); texel(x0, y1, c01); texel(x1, y1, c11);
+    const float sx = 1.f - tx, sy = 1.f - ty;
+    for (int k = 0; k < 3; k++) {
+      const float top = c00[k] * sx + c10[k] * tx, bot = c01[k] * sx + c11[k] * tx;
+      out[k] = top * sy + bot * ty;
+    }
+  }
+
   void lambert(const Light& li, const Material& m, Ray& ray) const {   // lights.cu:260-313
     if (li.type == AMBIENT) {
+      if (m.tex >= 0 && !m.for_ambient) return;
       for (int k = 0; k < 3; k++) ray.col[k] = ray.col[k] + m.col[k] * li.col[k];
       return;
     }
@@ -746,8 +831,13 @@ struct Tracer {
 
   void colorate(RayStack& st, const Material& m, Ray& ray) const {     // material.cu:10-101
     switch (m.type) {
-      case LAMBERT: for (const Light& li : sc.lights) lambert(li, m, ray); return;
-      case PHONG: for (const Light& li : sc.lights) phong(li, m, ray); return;
+      case LAMBERT:
+      case PHONG: {
+        Material mm = m;
+        if (m.tex >= 0) texture_colour(sc.textures[m.tex], m.bilinear, ray.uv[0], ray.uv[1], mm.col);
+        for (const Light& li : sc.lights) { if (mm.type == LAMBERT) lambert(li, mm, ray); else phong(li, mm, ray); }
+        return;
+      }
       case REFLECTIVE:
         if (ray.depth < sc.cam.depth) {
           float s = 2 * ddot(ray.dir, ray.n), r[3], sP[3], att[3];
@@ -856,6 +946,13 @@ struct oracle_info {
 static std::string g_err;
 const char* oracle_last_error() { return g_err.c_str(); }
 
+// Decoded pixels (RGB8, row 0 on top) of the texture the resources call `file_path`, for scenes loaded afterwards.
+void oracle_provide_texture(const char* file_path, int w, int h, const uint8_t* rgb) {
+  Texture t; t.w = w; t.h = h; t.rgb.assign(rgb, rgb + (size_t)w * h * 3);
+  g_provided_textures[file_path] = t;
+}
+void oracle_clear_textures() { g_provided_textures.clear(); }
+
 // base_dir: prefix for relative mesh paths ("" = cwd, as the reference resolves them).
 void* oracle_scene_load(const char* scene, const char* resources, int W, int H, int depth, const char* base_dir) {
   auto* sc = new Scene();
@@ -945,7 +1042,7 @@ void oracle_render_rows(void* h, int row_begin, int row_end, uint8_t* rgb, int32
 // ---- per-routine entry points for known-answer tests (one call = one reference routine) ----
 // triangle.cu:107-152. tri: 9 positions + 9 normals. ray_io: eye3 dir3 t. out: hit flag, t, ip3, n3.
 int oracle_intersect_triangle(const float* tri, const float* ray, float* out) {
-  Scene sc; Tri t; memcpy(t.v, tri, 36); memcpy(t.n, tri + 9, 36); t.mesh = 0; sc.tris.push_back(t);
+  Scene sc; Tri t; memset(&t, 0, sizeof t); memcpy(t.v, tri, 36); memcpy(t.n, tri + 9, 36); t.mesh = 0; sc.tris.push_back(t);
   Counters ct; Tracer tr(sc, ct); Ray r; memset(&r, 0, sizeof r);
   memcpy(r.eye, ray, 12); memcpy(r.dir, ray + 3, 12); r.t = ray[6]; r.tri = -1; r.sph = -1;
   bool hit = tr.hit_triangle(0, r, true);
@@ -969,7 +1066,7 @@ int oracle_node_accept(const float* box, const float* ray) {
 }
 // triangle.cu:61-105.
 int oracle_tri_overlaps_box(const float* verts, const float* box) {
-  Tri t; memcpy(t.v, verts, 36); return tri_overlaps_box(t, box, box + 3);
+  Tri t; memset(&t, 0, sizeof t); memcpy(t.v, verts, 36); return tri_overlaps_box(t, box, box + 3);
 }
 // vector.cu:147-156.
 void oracle_refract(const float* d, const float* n, float rori, float* out) { Tracer::refract(out, d, n, rori); }

@@ -33,7 +33,7 @@ ABI_SYMBOLS = (
     "rt_host_alloc", "rt_host_free", "rt_band_count", "rt_render_bands", "rt_dscene_get_info",
     "rt_comm_unique_id", "rt_comm_init_rank", "rt_comm_init_all", "rt_comm_destroy", "rt_comm_group_begin", "rt_comm_group_end",
     "rt_gather_bands", "rt_unpack_bands", "rt_render_frame_gathered",
-    "rt_write_png", "rt_strerror", "rt_last_error", "rt_version",
+    "rt_write_png", "rt_image_load", "rt_strerror", "rt_last_error", "rt_version",
 )
 
 
@@ -127,6 +127,7 @@ def lib():
         L.rt_render_frame_gathered.argtypes = [C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.c_int, C.c_int, C.c_void_p, C.c_uint,
                                                C.POINTER(Stats)]
         L.rt_write_png.argtypes = [C.c_char_p, C.c_int, C.c_int, C.c_void_p]
+        L.rt_image_load.argtypes = [C.c_char_p, C.POINTER(C.c_int), C.POINTER(C.c_int), C.c_void_p, C.c_size_t]
         L.rt_strerror.argtypes = [C.c_int]
         L.rt_strerror.restype = C.c_char_p
         L.rt_last_error.restype = C.c_char_p
@@ -352,6 +353,15 @@ def assemble_bands(tiles, height, band_rows):
     for r, tile in enumerate(tiles):
         rows = band_rows_of(height, band_rows, r, nranks)
         out[rows] = np.asarray(tile)[:len(rows)]
+    return out
+
+
+def load_image(path):
+    """A texture image (PNG or baseline JPEG) as the library decodes it: (H, W, 3) uint8, row 0 on top."""
+    w, h = C.c_int(), C.c_int()
+    _check(lib().rt_image_load(path.encode(), C.byref(w), C.byref(h), None, 0))
+    out = np.empty((h.value, w.value, 3), np.uint8)
+    _check(lib().rt_image_load(path.encode(), C.byref(w), C.byref(h), out.ctypes.data, out.nbytes))
     return out
 
 

@@ -218,6 +218,7 @@ extern "C" int rt_scene_upload(const rt_scene* s, int device, rt_dscene** out) {
   UP(nodes, s->nodes) UP(wnodes, s->wnodes) UP(leaf_refs, s->leaf_refs) UP(tri_geom, s->tri_geom) UP(tri_leaf, s->tri_leaf) UP(tri_shade, s->tri_shade)
   UP(spheres, s->spheres) UP(lights, s->lights) UP(materials, s->materials) UP(mat_index, s->mat_index)
   UP(mesh_mat_first, s->mesh_mat_first) UP(mesh_mat_count, s->mesh_mat_count)
+  if (!s->textures.empty()) { UP(tri_uv, s->tri_uv) UP(textures, s->textures) UP(texels, s->texels) }   // only scenes with texture materials
 #undef UP
   V.n_spheres = (int32_t)s->spheres.size(); V.n_lights = (int32_t)s->lights.size(); V.has_oct = s->nodes.empty() ? 0 : 1; V.n_wnodes = (int32_t)s->nodes.size();
   if ((rc = arena_reserve(d->ctx.arena, RT_COUNTER_BYTES, "rt_scene_upload")) != RT_OK) { d->ctx.release(); return rc; }
@@ -373,7 +374,8 @@ int launch_render(const SceneArrays& S, RenderCtx& ctx, RowMap rows, uint8_t* d_
   // Queues pay where rays scatter inside a glass mesh (glass bunny 1920x1080: 8.2 -> 4.3 ms, 512x512: 4.9 -> 3.7 ms; a tie
   // at 4K); mirrors and sphere scenes are faster on the lanes' stacks (their bounce rays stay neighbours, and the term
   // sort costs more than it saves).  RT_RENDER_QUEUED / RT_RENDER_STACKED force one way.
-  bool queued = bounce && rows.n_local > 0 && !(flags & RT_RENDER_LITERAL) &&
+  // (scenes with texture materials stay on the stacks: the queue variant of the kernel is not built with texture lookups)
+  bool queued = bounce && rows.n_local > 0 && !(flags & RT_RENDER_LITERAL) && !S.view.textures &&
                 ((flags & RT_RENDER_QUEUED) || (!(flags & RT_RENDER_STACKED) && S.dielectric_mesh));
   if (queued) {
     const int rc = prepare_wavefront(S, ctx, rows, stream, &queued);
@@ -397,7 +399,7 @@ int launch_render(const SceneArrays& S, RenderCtx& ctx, RowMap rows, uint8_t* d_
       const bool mesh = S.info.n_triangles > 0;
       // (a glass mesh rendered from queues: 8x8 tiles again - only its first generation is cut into tiles, and with the
       //  tiles dealt out from the middle of the picture that one is 2 to 8 % faster on the large tiles at 512x512 .. 1280x720)
-      const bool from_queues = (flags & RT_RENDER_QUEUED) || (!(flags & RT_RENDER_STACKED) && S.dielectric_mesh);
+      const bool from_queues = !S.view.textures && ((flags & RT_RENDER_QUEUED) || (!(flags & RT_RENDER_STACKED) && S.dielectric_mesh));
       rows.small = forced ? (forced == 4)
                           : ((S.info.n_triangles >= 20000 && tiles < 5120) ||
                              (S.info.has_bounce_materials && mesh && tiles < 16384 && !from_queues));

@@ -40,6 +40,8 @@ extern "C" const char* rt_strerror(int status) {
   }
 }
 
+bool rt_decode_image_file(const std::string& path, int& W, int& H, std::vector<uint8_t>& rgb, std::string& err);   // rt_image.cpp
+
 namespace {
 
 using Clock = std::chrono::steady_clock;
@@ -173,6 +175,7 @@ Json read_json_file(const std::string& path) {
 struct HostMesh {
   std::vector<float> pos;        // 3 per OBJ position index
   std::vector<float> nrm;        // 3 per position index (first normal seen in a face, or computed)
+  std::vector<float> uv;         // 2 per position index: the `vt` of the first face corner that uses the position (parsing.cu:106-108), else 0
   std::vector<uint8_t> used;     // position index referenced by a face
   std::vector<int32_t> face;     // 3 position indices per face
   std::vector<float> face_n;     // 3 per face
@@ -251,7 +254,7 @@ HostMesh load_obj(const std::string& path) {
     size_t n = strlen(word);
     return (size_t)(e - b) == n && memcmp(b, word, n) == 0;
   };
-  std::vector<float> vn; size_t n_vt = 0;
+  std::vector<float> vn, vt;
   // skip to the first vertex
   for (;;) {
     fetch();
@@ -267,27 +270,28 @@ HostMesh load_obj(const std::string& path) {
     const char *hb, *he; sp.next(' ', hb, he);
     auto is = [&](const char* w) { size_t n = strlen(w); return (size_t)(he - hb) == n && memcmp(hb, w, n) == 0; };
     if (state == V) { if (is("v")) { for (int k = 0; k < 3; k++) m.pos.push_back(tok_float(sp)); continue; } state = VT; }
-    if (state == VT) { if (is("vt")) { tok_float(sp); tok_float(sp); n_vt++; continue; } state = VN; }
+    if (state == VT) { if (is("vt")) { vt.push_back(tok_float(sp)); vt.push_back(tok_float(sp)); continue; } state = VN; }
     if (state == VN) { if (is("vn")) { for (int k = 0; k < 3; k++) vn.push_back(tok_float(sp)); continue; } state = SEEK_F; }
     if (state == SEEK_F) {
       if (!is("f")) { if (eof) throw Fail{RT_ERR_PARSE, "no face lines in " + path}; continue; }
       state = F;
       const size_t nv = m.pos.size() / 3;
-      m.used.assign(nv, 0); m.nrm.assign(3 * nv, 0.f); first_normal.assign(nv, -1);
+      m.used.assign(nv, 0); m.nrm.assign(3 * nv, 0.f); m.uv.assign(2 * nv, 0.f); first_normal.assign(nv, -1);
       m.file_normals = !vn.empty();
     }
     if (state == F) {
       if (!is("f")) { state = DONE; break; }
       const size_t nv = m.used.size();
       for (int c = 0; c < 3; c++) {
-        long vin, nin = -1;
+        long vin, nin = -1, uvin = -1;
         if (m.file_normals) vin = tok_index(sp, '/') - 1; else vin = tok_index(sp, ' ') - 1;
-        if (n_vt) (void)tok_index(sp, '/');
+        if (!vt.empty()) uvin = tok_index(sp, '/') - 1;
         else if (m.file_normals) { const char *b, *e; sp.next('/', b, e); }
         if (m.file_normals) nin = tok_index(sp, ' ') - 1;
         if (vin < 0 || (size_t)vin >= nv) throw Fail{RT_ERR_PARSE, "face references a missing vertex in " + path};
         if (!m.used[vin]) {
           m.used[vin] = 1;
+          if (uvin >= 0 && (size_t)uvin < vt.size() / 2) { m.uv[2 * vin] = vt[2 * uvin]; m.uv[2 * vin + 1] = vt[2 * uvin + 1]; }
           if (nin != -1) {
             if (nin < 0 || (size_t)nin >= vn.size() / 3) throw Fail{RT_ERR_PARSE, "face references a missing normal in " + path};
             m.nrm[3 * vin + 0] = vn[3 * nin + 0]; m.nrm[3 * vin + 1] = vn[3 * nin + 1]; m.nrm[3 * vin + 2] = vn[3 * nin + 2];
@@ -533,15 +537,28 @@ void tree_summary(const rt_scene& sc, int32_t id, int depth, rt_scene_info& o) {
 struct MaterialTable {
   std::vector<RtMaterial> mats;
   std::map<std::string, int> by_name;
+  std::vector<std::string> texture_of;               // per material: name of its texture ("" = none)
+  std::map<std::string, std::string> texture_file;   // texture name -> file path
 };
 
 MaterialTable load_resources(const std::string& path) {   // parsing.cu:177-269
   MaterialTable T;
   const Json root = read_json_file(path);
   for (size_t i = 0; i < root.keys.size(); i++) {
+    if (root.keys[i] == "textures") {   // {"__type__": "color_texture", "name": ..., "file_path": ...}
+      for (const Json& entry : root.items[i].items) {
+        std::string name, file;
+        for (size_t k = 0; k < entry.keys.size(); k++) {
+          if (entry.keys[k] == "name") name = entry.items[k].text;
+          else if (entry.keys[k] == "file_path") file = entry.items[k].text;
+        }
+        if (!name.empty()) T.texture_file[name] = file;
+      }
+      continue;
+    }
     if (root.keys[i] != "materials") continue;
     for (const Json& entry : root.items[i].items) {
-      std::string type, name; std::vector<float> col, att; int shininess = 0; float ior = 0.f;
+      std::string type, name, texture, filtering; std::vector<float> col, att; int shininess = 0; float ior = 0.f; bool for_ambient = false;
       for (size_t k = 0; k < entry.keys.size(); k++) {
         const std::string& key = entry.keys[k]; const Json& val = entry.items[k];
         if (key == "__type__" || key == "brdf") type = val.text;
@@ -549,6 +566,9 @@ MaterialTable load_resources(const std::string& path) {   // parsing.cu:177-269
         else if (key == "color") val.floats(col);
         else if (key == "attenuation") val.floats(att);
         else if (key == "refraction_index") ior = val.as_float();
+        else if (key == "color_texture") texture = val.text;
+        else if (key == "texture_filtering") filtering = val.text;
+        else if (key == "use_for_ambient") for_ambient = val.text == "true";
         else if (key == "brdfParams") {
           for (size_t q = 0; q < val.keys.size(); q++) if (val.keys[q] == "shininess") shininess = val.items[q].as_int();
         }
@@ -559,13 +579,24 @@ MaterialTable load_resources(const std::string& path) {   // parsing.cu:177-269
       else if (type == "reflective_material") m.type = RT_REFLECTIVE;
       else if (type == "dielectric_material") { m.type = RT_DIELECTRIC; m.param = ior; }
       else continue;
-      // Entries without a colour (the texture-flavoured ones) cannot be evaluated: the reference
-      // reads past the end of an empty vector for them.  They stay unknown to scenes.
+      if (!texture.empty() && (m.type == RT_LAMBERT || m.type == RT_PHONG)) {
+        // `brdf_color_texture_material`: Lambert or Blinn-Phong whose colour is looked up in a texture.  The reference
+        // has no behaviour for these (its parser reads past the end of their missing colour, its TextureMaterial is a
+        // stub); what they do here is this library's definition, stated in rt_kernels.h (texture_colour).
+        m.type = m.type == RT_LAMBERT ? RT_TEX_LAMBERT : RT_TEX_PHONG;
+        const uint32_t flags = (filtering == "bilinear" ? RT_TEX_BILINEAR : 0u) | (for_ambient ? RT_TEX_AMBIENT : 0u);
+        memcpy(&m.att[1], &flags, 4);
+        T.by_name[name] = (int)T.mats.size();
+        T.mats.push_back(m); T.texture_of.push_back(texture);
+        continue;
+      }
+      // Other entries without a colour cannot be evaluated: the reference reads past the end of an empty vector for
+      // them.  They stay unknown to scenes.
       if (col.size() < 3) continue;
       if (m.type == RT_DIELECTRIC && att.size() < 3) continue;
       for (int c = 0; c < 3; c++) { m.col[c] = col[c]; if (m.type == RT_DIELECTRIC) m.att[c] = att[c]; }
       T.by_name[name] = (int)T.mats.size();
-      T.mats.push_back(m);
+      T.mats.push_back(m); T.texture_of.push_back("");
     }
   }
   return T;
@@ -640,6 +671,7 @@ void load_scene_into(rt_scene& sc, const std::string& scene_path, const std::str
             g.mesh = mesh_id;
             sc.tri_geom.push_back(g); sc.tri_shade.push_back(s);
             for (int c = 0; c < 3; c++) for (int k = 0; k < 3; k++) { sc.tri_verts.push_back(p[c][k]); sc.tri_normals.push_back(n[c][k]); }
+            for (int c = 0; c < 3; c++) { sc.tri_uv.push_back(m.uv[2 * m.face[3 * f + c]]); sc.tri_uv.push_back(m.uv[2 * m.face[3 * f + c] + 1]); }
           }
         }
       }
@@ -685,6 +717,31 @@ void load_scene_into(rt_scene& sc, const std::string& scene_path, const std::str
   }
   if (!have_camera || eye.size() < 3 || up.size() < 3 || target.size() < 3)
     throw Fail{RT_ERR_PARSE, "scene has no usable camera: " + scene_path};
+
+  // textures of the materials some object uses: decoded once each, RGB8 packed one texel to a word
+  {
+    std::map<std::string, int> loaded;
+    auto use = [&](int32_t mi) {
+      const std::string& tname = T.texture_of[mi];
+      if (tname.empty()) return;
+      auto it = loaded.find(tname);
+      if (it == loaded.end()) {
+        auto tf = T.texture_file.find(tname);
+        if (tf == T.texture_file.end()) throw Fail{RT_ERR_PARSE, "material uses the unknown texture '" + tname + "' in " + res_path};
+        const std::string path = (!tf->second.empty() && tf->second[0] == '/') ? tf->second : base_dir + tf->second;
+        int tw = 0, th = 0; std::vector<uint8_t> rgb; std::string err;
+        if (!rt_decode_image_file(path, tw, th, rgb, err)) throw Fail{err.rfind("No ", 0) == 0 ? RT_ERR_IO : RT_ERR_PARSE, err};
+        RtTexture t; t.first = (uint32_t)sc.texels.size(); t.width = (uint32_t)tw; t.height = (uint32_t)th; t.pad = 0;
+        for (size_t q = 0; q < (size_t)tw * th; q++) sc.texels.push_back((uint32_t)rgb[3 * q] | ((uint32_t)rgb[3 * q + 1] << 8) | ((uint32_t)rgb[3 * q + 2] << 16));
+        it = loaded.emplace(tname, (int)sc.textures.size()).first;
+        sc.textures.push_back(t);
+      }
+      const uint32_t index = (uint32_t)it->second;
+      memcpy(&sc.materials[mi].att[0], &index, 4);
+    };
+    for (auto& mm : sphere_mats) for (int32_t mi : mm) use(mi);
+    for (auto& mm : mesh_mats) for (int32_t mi : mm) use(mi);
+  }
 
   // material lists: spheres first, then meshes
   for (size_t s = 0; s < sc.spheres.size(); s++) {

@@ -18,7 +18,11 @@
 #define RT_OCT_STACK 20
 #define RT_MAX_LEVELS 3
 
-enum RtMatType { RT_LAMBERT = 0, RT_PHONG = 1, RT_REFLECTIVE = 2, RT_DIELECTRIC = 3 };
+// RT_TEX_*: the colour of the material comes from a texture (resources.json `brdf_color_texture_material`); the reference
+// declares such a material (material.cuh:10, material.cu:263-301) but never loads an image or shades with one.
+enum RtMatType { RT_LAMBERT = 0, RT_PHONG = 1, RT_REFLECTIVE = 2, RT_DIELECTRIC = 3, RT_TEX_LAMBERT = 4, RT_TEX_PHONG = 5 };
+#define RT_TEX_BILINEAR 1u   // flags of a texture material (bits of RtMaterial::att[1]): filtering, and whether the ambient light sees the texture
+#define RT_TEX_AMBIENT 2u
 enum RtLightType { RT_PUNCTUAL = 0, RT_SPOT = 1, RT_AMBIENT = 2, RT_DIRECTIONAL = 3 };
 
 // 96 B, passed to kernels by value (lives in SGPRs / kernarg, never re-read from HBM per pixel).
@@ -31,8 +35,11 @@ struct RtCamera {
 
 struct RtMaterial {   // 32 B
   float col[3]; float param;
-  float att[3]; int32_t type;
+  float att[3]; int32_t type;   // texture materials: att[0] = bits of the texture's index, att[1] = bits of the RT_TEX_* flags
 };
+
+// A texture: `width * height` texels (R | G << 8 | B << 16, row 0 on top) starting at texel `first` of the scene's texel array.
+struct RtTexture { uint32_t first, width, height, pad; };
 
 struct RtLight {      // 48 B
   float col[3]; int32_t type;
@@ -96,6 +103,9 @@ struct rt_scene {
   std::vector<RtTriLeaf> tri_leaf;                // intersection records repeated in leaf order (index space of leaf_refs), plus one pad record
   std::vector<RtTriShade> tri_shade;
   std::vector<float> tri_verts, tri_normals;      // n*9 each, as the reference uploads them
+  std::vector<float> tri_uv;                      // n*6: texture coordinates of the three corners (parsing.cu:54-63,102-108; zeros without `vt` lines)
+  std::vector<RtTexture> textures;                // the textures some material of the scene uses
+  std::vector<uint32_t> texels;
   rt_scene_info info;
   int32_t max_pushes_per_hit = 0;                 // most rays one hit can push: 1 per reflective, 2 per dielectric material of a primitive
   int32_t dielectric_mesh = 0;                    // some mesh carries a dielectric material

@@ -112,12 +112,21 @@ __global__ __launch_bounds__(RT_BLOCK) void render_tiles(const RtDeviceView S, c
           mfirst = S.mesh_mat_first[mesh]; mcount = S.mesh_mat_count[mesh];
         } else { mfirst = S.spheres[-2 - hit.prim].mat_first; mcount = S.spheres[-2 - hit.prim].mat_count; }
         for (int32_t mi = 0; mi < mcount; mi++) {   // ray.cu:77-85
-          const RtMaterial M = S.materials[S.mat_index[mfirst + mi]];
+          RtMaterial M = S.materials[S.mat_index[mfirst + mi]];
+          bool seen_by_ambient = true;
+          if (M.type >= RT_TEX_LAMBERT) {   // a texture material: Lambert / Blinn-Phong with the colour looked up (rt_kernels.h)
+            float tu, tv;
+            hit_uv(S.tri_uv, hit, N, tu, tv);
+            const uint32_t flags = __float_as_uint(M.att[1]);
+            const RtVec3 tc = texture_colour(S.textures, S.texels, __float_as_uint(M.att[0]), flags, tu, tv);
+            M.col[0] = tc.x; M.col[1] = tc.y; M.col[2] = tc.z;
+            M.type -= RT_TEX_LAMBERT; seen_by_ambient = (flags & RT_TEX_AMBIENT) != 0u;
+          }
           if (M.type == RT_LAMBERT || M.type == RT_PHONG) {   // material.cu:15-24, lights.cu:260-367
             for (int32_t li = 0; li < S.n_lights; li++) {
               const RtLight L = S.lights[li];
               if (L.type == RT_AMBIENT) {
-                if (M.type == RT_LAMBERT) for (int k = 0; k < 3; k++) colr[k] = colr[k] + M.col[k] * L.col[k];
+                if (M.type == RT_LAMBERT && seen_by_ambient) for (int k = 0; k < 3; k++) colr[k] = colr[k] + M.col[k] * L.col[k];
                 continue;
               }
               RtVec3 l; float ldist;

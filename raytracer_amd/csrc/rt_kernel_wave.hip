@@ -812,6 +812,7 @@ struct ShadeState {
   float hit_t;                       // distance of the hit being shaded (Beer attenuation)
   int32_t mfirst, mcount, mi, li;    // material list of the hit primitive, (material, light) cursor
   uint32_t vis_known, vis_occluded;  // per light (first 32): shadow test already traced for this hit point
+  float tu, tv;                      // texture coordinates of the hit (variants for scenes with texture materials only)
   RtVec3 att; float level0, level1, level2; int32_t nlevel, depth;   // BOUNCE only (no arrays: the state must stay in registers)
   __device__ __forceinline__ float level_at(int i) const {
     float a = level0, b = level1, c = level2;
@@ -828,23 +829,25 @@ struct ShadeState {
 #define RT_SHADE_INTS(X) X(13, mfirst) X(14, mcount) X(15, mi) X(16, li) X(17, vis_known) X(18, vis_occluded)
 #define RT_SHADE_BOUNCE_FLOATS(X) X(19, att.x) X(20, att.y) X(21, att.z) X(22, level0) X(23, level1) X(24, level2) X(25, color.x) X(26, color.y) X(27, color.z)
 #define RT_SHADE_BOUNCE_INTS(X) X(28, nlevel) X(29, depth)
-template <bool BOUNCE>
+template <bool BOUNCE, bool TEX>
 __device__ __forceinline__ void park(const ShadeState<BOUNCE>& s, float* lds) {
   uint32_t* ldu = (uint32_t*)lds;
 #define PUT_F(k, f) lds[(k) * RT_WBLOCK] = s.f;
 #define PUT_I(k, f) ldu[(k) * RT_WBLOCK] = (uint32_t)s.f;
   RT_SHADE_FLOATS(PUT_F) RT_SHADE_INTS(PUT_I)
   if (BOUNCE) { RT_SHADE_BOUNCE_FLOATS(PUT_F) RT_SHADE_BOUNCE_INTS(PUT_I) }
+  if (TEX) { PUT_F(ShadeState<BOUNCE>::WORDS, tu) PUT_F(ShadeState<BOUNCE>::WORDS + 1, tv) }
 #undef PUT_F
 #undef PUT_I
 }
-template <bool BOUNCE>
+template <bool BOUNCE, bool TEX>
 __device__ __forceinline__ void unpark(ShadeState<BOUNCE>& s, const float* lds) {
   const uint32_t* ldu = (const uint32_t*)lds;
 #define GET_F(k, f) s.f = lds[(k) * RT_WBLOCK];
 #define GET_I(k, f) s.f = (decltype(s.f))ldu[(k) * RT_WBLOCK];
   RT_SHADE_FLOATS(GET_F) RT_SHADE_INTS(GET_I)
   if (BOUNCE) { RT_SHADE_BOUNCE_FLOATS(GET_F) RT_SHADE_BOUNCE_INTS(GET_I) }
+  if (TEX) { GET_F(ShadeState<BOUNCE>::WORDS, tu) GET_F(ShadeState<BOUNCE>::WORDS + 1, tv) }
 #undef GET_F
 #undef GET_I
 }
@@ -862,6 +865,7 @@ struct RtWaveArgs {
   const float4* tri_geom; const float4* tri_shade;
   const RtSphere* spheres; const RtLight* lights; const RtMaterial* materials; const int32_t* mat_index;
   const int32_t* mesh_mat_first; const int32_t* mesh_mat_count;
+  const float* tri_uv; const RtTexture* textures; const uint32_t* texels;   // scenes with texture materials only
   int n_spheres, n_lights, has_oct, n_wnodes;
   uint8_t* rgb; int32_t* ids; float* ts; unsigned long long* counters_all; int tally;
   // Tiles of the launch and how they are dealt to the chip's dies (see tile_of): tiles per row / column, strips of
@@ -895,7 +899,9 @@ __device__ __forceinline__ T late_struct(size_t offset) {
 // DENSE (plain variant only): compiled for one more wave per SIMD, at the price of spilled registers in the shading code.
 // It pays for big frames of a heavy mesh, whose walks dominate (meshDragon 4K: 2.71 -> 2.61 ms), not for small frames
 // (1920x1080: 1.24 -> 1.28 ms) nor where shading weighs (sphere scenes: + 50 %); the launch chooses.
-template <bool BOUNCE, bool COUNT, bool QUEUES, bool DENSE = false>
+// TEX: the scene has texture materials (two more words of shading state, a texel fetch per material and light: variants
+// of their own, so that every other scene runs the kernels it ran before).
+template <bool BOUNCE, bool COUNT, bool QUEUES, bool DENSE = false, bool TEX = false>
 __global__ __launch_bounds__(RT_WBLOCK, BOUNCE ? RT_WAVES_PER_SIMD_BOUNCE : (DENSE ? RT_WAVES_PER_SIMD + 1 : RT_WAVES_PER_SIMD)) void render_wave(
     const float4* __restrict__ nodes, const float4* __restrict__ tri_leaf, const RtWaveArgs A) {
   const RtSphere* __restrict__ spheres = A.spheres;
@@ -907,7 +913,8 @@ __global__ __launch_bounds__(RT_WBLOCK, BOUNCE ? RT_WAVES_PER_SIMD_BOUNCE : (DEN
   // The counters and the finished colour only ever live there: they are touched a few times per pixel, and as values that
   // every round of the main loop carries along they cost six registers (in the six-wave variant: six spill stores per
   // round) for nothing.
-  __shared__ float parked[(ShadeState<BOUNCE>::WORDS + 6) * RT_WBLOCK];
+  constexpr int SW = ShadeState<BOUNCE>::WORDS + (TEX ? 2 : 0);   // words of parked shading state
+  __shared__ float parked[(SW + 6) * RT_WBLOCK];
   uint32_t (*pack)[48] = (uint32_t (*)[48])parked;   // [wave][48]
   // The thread's index within its workgroup.  It is handed over in a register at the start and cannot be asked for again;
   // a workgroup of one wave derives it anew wherever it is needed (two instructions) instead of keeping it - and what is
@@ -921,7 +928,7 @@ __global__ __launch_bounds__(RT_WBLOCK, BOUNCE ? RT_WAVES_PER_SIMD_BOUNCE : (DEN
 #define LANE() (tid_kept & 63)
 #endif
 #define MY_PARK() (&parked[TID()])
-#define MY_COUNTS() ((uint32_t*)MY_PARK() + ShadeState<BOUNCE>::WORDS * RT_WBLOCK)   /* rays, shadow rays, rays traced, finished colour */
+#define MY_COUNTS() ((uint32_t*)MY_PARK() + SW * RT_WBLOCK)   /* rays, shadow rays, rays traced, finished colour */
   MY_COUNTS()[0] = 0u; MY_COUNTS()[RT_WBLOCK] = 0u; MY_COUNTS()[2 * RT_WBLOCK] = 0u; MY_COUNTS()[3 * RT_WBLOCK] = 0u;
   enum { N_RAYS = 0, N_SHADOW = 1, N_TRACED = 2 };
   auto count = [&](int which) { __hip_atomic_fetch_add(MY_COUNTS() + which * RT_WBLOCK, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); };
@@ -1017,7 +1024,7 @@ __global__ __launch_bounds__(RT_WBLOCK, BOUNCE ? RT_WAVES_PER_SIMD_BOUNCE : (DEN
   ShadeState<BOUNCE> sh;
   sh.P = {0, 0, 0}; sh.N = {0, 0, 1}; sh.view = tr_d;
   sh.colr = {0.f, 0.f, 0.f}; sh.color = {0.f, 0.f, 0.f}; sh.level1 = 0.f; sh.level2 = 0.f;
-  sh.hit_t = RT_INF; sh.mfirst = 0; sh.mcount = 0; sh.mi = 0; sh.li = 0; sh.vis_known = 0; sh.vis_occluded = 0;
+  sh.hit_t = RT_INF; sh.mfirst = 0; sh.mcount = 0; sh.mi = 0; sh.li = 0; sh.vis_known = 0; sh.vis_occluded = 0; sh.tu = 0.f; sh.tv = 0.f;
   sh.att = {1.f, 1.f, 1.f}; sh.level0 = c.scene_refr; sh.nlevel = 0; sh.depth = 0;
   BounceRay rstack[BOUNCE ? RT_RAY_STACK : 1];
   int rsp = 0;
@@ -1095,17 +1102,17 @@ __global__ __launch_bounds__(RT_WBLOCK, BOUNCE ? RT_WAVES_PER_SIMD_BOUNCE : (DEN
       const bool want = phase != PH_DONE;
       // the instrumented variant walks shadow rays to the end, as the reference does, so that its test counts match
       const float stop_t = (phase == PH_SHADOW && !COUNT) ? tr_stop : -1.f;
-      park<BOUNCE>(sh, MY_PARK());
+      park<BOUNCE, TEX>(sh, MY_PARK());
       asm volatile("" ::: "memory");
       if (CLASSES) {
-        float* const bary = parked + (ShadeState<BOUNCE>::WORDS + 4) * RT_WBLOCK + (RT_WBLOCK == 64 ? 0 : (TID() & ~63));   // the wave's columns of the two barycentric words
+        float* const bary = parked + (SW + 4) * RT_WBLOCK + (RT_WBLOCK == 64 ? 0 : (TID() & ~63));   // the wave's columns of the two barycentric words
         traced = in_mask(trace_class(nodes, n_wnodes, tri_leaf, spheres, n_spheres, has_oct != 0, want, tr_e, tr_d, stop_t, h, st, bary));
         asm volatile("" ::: "memory");
         h.bet = bary[LANE()]; h.gam = bary[RT_WBLOCK + LANE()];   // (only meaningful, and only used, when a triangle was hit)
       }
       else trace_wave<COUNT>(nodes, n_wnodes, tri_leaf, spheres, n_spheres, has_oct != 0, want, tr_e, tr_d, stop_t, h, st, LANE(), tl, cull_sh + 16 * (TID() >> 6));
       asm volatile("" ::: "memory");
-      unpark<BOUNCE>(sh, MY_PARK());
+      unpark<BOUNCE, TEX>(sh, MY_PARK());
     }
     if (traced) count(N_TRACED);
     const rt_kernarg_ptr ka = late_args();   // one opaque copy for the whole shading phase: its loads go out together
@@ -1132,6 +1139,7 @@ __global__ __launch_bounds__(RT_WBLOCK, BOUNCE ? RT_WAVES_PER_SIMD_BOUNCE : (DEN
         RtDeviceView S;   // view handed to the helpers of rt_kernels.h
         S.tri_geom = LATE_AT(ka, tri_geom); S.tri_shade = LATE_AT(ka, tri_shade); S.spheres = spheres;
         surface(S, tr_e, tr_d, h, sh.P, sh.N);
+        if (TEX) hit_uv(LATE_AT(ka, tri_uv), h, sh.N, sh.tu, sh.tv);
         if (h.prim >= 0) {
           const int32_t mesh = (int32_t)__float_as_uint(S.tri_geom[3 * h.prim + 2].y);
           sh.mfirst = LATE_AT(ka, mesh_mat_first)[mesh]; sh.mcount = LATE_AT(ka, mesh_mat_count)[mesh];
@@ -1171,14 +1179,21 @@ __global__ __launch_bounds__(RT_WBLOCK, BOUNCE ? RT_WAVES_PER_SIMD_BOUNCE : (DEN
           } else phase = PH_DONE;
           break;
         }
-        const RtMaterial M = LATE_AT(ka, materials)[LATE_AT(ka, mat_index)[sh.mfirst + sh.mi]];
+        RtMaterial M = LATE_AT(ka, materials)[LATE_AT(ka, mat_index)[sh.mfirst + sh.mi]];
+        bool seen_by_ambient = true;
+        if (TEX && M.type >= RT_TEX_LAMBERT) {   // a texture material: Lambert / Blinn-Phong with the colour looked up (rt_kernels.h)
+          const uint32_t tflags = __float_as_uint(M.att[1]);
+          const RtVec3 tc = texture_colour(LATE_AT(ka, textures), LATE_AT(ka, texels), __float_as_uint(M.att[0]), tflags, sh.tu, sh.tv);
+          M.col[0] = tc.x; M.col[1] = tc.y; M.col[2] = tc.z;
+          M.type -= RT_TEX_LAMBERT; seen_by_ambient = (tflags & RT_TEX_AMBIENT) != 0u;
+        }
         const RtVec3 P = sh.P, N = sh.N;
         if (M.type == RT_LAMBERT || M.type == RT_PHONG) {   // material.cu:15-24, lights.cu:260-367
           const int li = sh.li;
           if (li >= LATE_AT(ka, n_lights)) { sh.mi++; sh.li = 0; continue; }
           const RtLight L = LATE_AT(ka, lights)[li];
           if (L.type == RT_AMBIENT) {
-            if (M.type == RT_LAMBERT) {
+            if (M.type == RT_LAMBERT && seen_by_ambient) {
               sh.colr.x = sh.colr.x + M.col[0] * L.col[0]; sh.colr.y = sh.colr.y + M.col[1] * L.col[1]; sh.colr.z = sh.colr.z + M.col[2] * L.col[2];
             }
             sh.li++; continue;
@@ -1369,10 +1384,16 @@ void rt_launch_wave_kernel(const RtDeviceView& V, const RowMap& rows, bool bounc
   A.cam = V.cam; A.rows = rows; A.tri_geom = V.tri_geom; A.tri_shade = V.tri_shade;
   A.spheres = V.spheres; A.lights = V.lights; A.materials = V.materials; A.mat_index = V.mat_index;
   A.mesh_mat_first = V.mesh_mat_first; A.mesh_mat_count = V.mesh_mat_count;
+  A.tri_uv = V.tri_uv; A.textures = V.textures; A.texels = V.texels;
   A.n_spheres = V.n_spheres; A.n_lights = V.n_lights; A.has_oct = V.has_oct; A.n_wnodes = V.n_wnodes;
   A.rgb = rgb; A.ids = ids; A.ts = ts; A.counters_all = counters; A.tally = tally ? 1 : 0; A.wf = wf;
 #define LAUNCH(B, C, Q) hipLaunchKernelGGL((render_wave<B, C, Q>), grid, block, 0, stream, V.wnodes, V.tri_leaf, A)
-  if (wf.enabled) { if (count) LAUNCH(true, true, true); else LAUNCH(true, false, true); }
+  if (V.textures) {   // (never from queues: rt_device.hip keeps scenes with texture materials on the stacks)
+#define LAUNCH_TEX(B, C) hipLaunchKernelGGL((render_wave<B, C, false, false, true>), grid, block, 0, stream, V.wnodes, V.tri_leaf, A)
+    if (bounce && count) LAUNCH_TEX(true, true); else if (bounce) LAUNCH_TEX(true, false); else if (count) LAUNCH_TEX(false, true); else LAUNCH_TEX(false, false);
+#undef LAUNCH_TEX
+  }
+  else if (wf.enabled) { if (count) LAUNCH(true, true, true); else LAUNCH(true, false, true); }
   else if (bounce && count) LAUNCH(true, true, false);
   else if (bounce) LAUNCH(true, false, false);
   else if (count) LAUNCH(false, true, false);

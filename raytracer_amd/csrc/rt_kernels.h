@@ -28,6 +28,9 @@ struct RtDeviceView {
   const int32_t* mesh_mat_first;
   const int32_t* mesh_mat_count;
   int32_t n_spheres, n_lights, has_oct, pad;
+  const float* tri_uv;          // 6 per triangle, indexed by triangle id; nullptr (like the next two) in scenes without texture materials
+  const RtTexture* textures;
+  const uint32_t* texels;
 };
 
 // Which image rows a launch renders and where they are stored.  Local row lr (0..n_local) is image
@@ -145,6 +148,62 @@ __device__ __forceinline__ void surface(const RtDeviceView& S, const RtVec3& eye
     nx = n.x; ny = n.y; nz = n.z;
   }
   P.x = px; P.y = py; P.z = pz; N.x = nx; N.y = ny; N.z = nz;
+}
+
+// ---- texture materials -----------------------------------------------------------------------------------------------
+// The reference declares them (resources.json `brdf_color_texture_material`, material.cuh:10 TEXTURE) but has no
+// behaviour: its loader is a stub and `colorate` has no case for them.  What follows is this library's definition, the
+// same float operations in the CPU restatement the tests compare with:
+//   * texture coordinates of a hit: on a triangle the corners' `vt` interpolated like the normals, (uv0 alp + uv1 bet) +
+//     uv2 gam; on a sphere longitude and latitude of the unit normal, u = 0.5 + atan2f(n.z, n.x) / 2pi, v = 0.5 + asinf(n.y) / pi;
+//   * u and v repeat (x - floorf(x)); v = 1 is the image's top row;
+//   * nearest_neighbor: texel (int)(u W), (int)((1 - v) H); bilinear: the four texels around (u W - 0.5, (1 - v) H - 0.5),
+//     wrapped, blended first along x then along y; a texel's channel is its byte / 255;
+//   * the colour takes the place of the material's colour in the Lambert / Blinn-Phong sums (material.cu:15-24,
+//     lights.cu:260-367); the ambient light sees it only with `use_for_ambient`.
+__device__ __forceinline__ void hit_uv(const float* __restrict__ tri_uv, const Hit& h, const RtVec3& N, float& u, float& v) {
+  if (h.prim >= 0) {
+    const float* t = tri_uv + 6 * (size_t)h.prim;
+    const float alp = 1 - h.bet - h.gam;
+    u = (t[0] * alp + t[2] * h.bet) + t[4] * h.gam;
+    v = (t[1] * alp + t[3] * h.bet) + t[5] * h.gam;
+  } else {
+    u = 0.5f + atan2f(N.z, N.x) * 0.15915494f;
+    v = 0.5f + asinf(N.y < -1.f ? -1.f : (N.y > 1.f ? 1.f : N.y)) * 0.31830987f;
+  }
+}
+
+__device__ __forceinline__ RtVec3 texel_rgb(uint32_t w) {
+  return {(float)(w & 255u) / 255.f, (float)((w >> 8) & 255u) / 255.f, (float)((w >> 16) & 255u) / 255.f};
+}
+
+__device__ __forceinline__ RtVec3 texture_colour(const RtTexture* __restrict__ textures, const uint32_t* __restrict__ texels, uint32_t index,
+                                                 uint32_t flags, float u, float v) {
+  const RtTexture T = textures[index];
+  const uint32_t* px = texels + T.first;
+  const int W = (int)T.width, H = (int)T.height;
+  if (!(u - u == 0.f) || !(v - v == 0.f)) { u = 0.f; v = 0.f; }   // (NaN or infinite coordinates: the first texel)
+  u = u - floorf(u); v = v - floorf(v);
+  const float fx = u * (float)W, fy = (1.f - v) * (float)H;
+  if (!(flags & RT_TEX_BILINEAR)) {
+    int x = (int)fx, y = (int)fy;
+    x = x < W ? x : W - 1; y = y < H ? y : H - 1;
+    return texel_rgb(px[(size_t)y * W + x]);
+  }
+  const float gx = fx - 0.5f, gy = fy - 0.5f;
+  const float x0f = floorf(gx), y0f = floorf(gy);
+  const float tx = gx - x0f, ty = gy - y0f;
+  int x0 = (int)x0f, y0 = (int)y0f;
+  int x1 = x0 + 1, y1 = y0 + 1;
+  x0 = x0 < 0 ? x0 + W : x0; y0 = y0 < 0 ? y0 + H : y0;
+  x1 = x1 >= W ? x1 - W : x1; y1 = y1 >= H ? y1 - H : y1;
+  x0 = x0 < W ? x0 : W - 1; y0 = y0 < H ? y0 : H - 1;
+  const RtVec3 c00 = texel_rgb(px[(size_t)y0 * W + x0]), c10 = texel_rgb(px[(size_t)y0 * W + x1]);
+  const RtVec3 c01 = texel_rgb(px[(size_t)y1 * W + x0]), c11 = texel_rgb(px[(size_t)y1 * W + x1]);
+  const float sx = 1.f - tx, sy = 1.f - ty;
+  const RtVec3 top = {c00.x * sx + c10.x * tx, c00.y * sx + c10.y * tx, c00.z * sx + c10.z * tx};
+  const RtVec3 bot = {c01.x * sx + c11.x * tx, c01.y * sx + c11.y * tx, c01.z * sx + c11.z * tx};
+  return {top.x * sy + bot.x * ty, top.y * sy + bot.y * ty, top.z * sy + bot.z * ty};
 }
 
 // vector.cu:147-156

@@ -53,8 +53,15 @@ def lib():
         L.oracle_tri_overlaps_box.argtypes = [C.c_void_p, C.c_void_p]
         L.oracle_tri_overlaps_box.restype = C.c_int
         L.oracle_refract.argtypes = [C.c_void_p, C.c_void_p, C.c_float, C.c_void_p]
+        L.oracle_provide_texture.argtypes = [C.c_char_p, C.c_int, C.c_int, C.c_void_p]
         _LIB = L
     return _LIB
+
+
+def provide_texture(file_path, rgb):
+    """Hands the checker the decoded pixels ((H, W, 3) uint8) of the texture the resources call `file_path`."""
+    rgb = np.ascontiguousarray(rgb, np.uint8)
+    lib().oracle_provide_texture(file_path.encode(), rgb.shape[1], rgb.shape[0], rgb.ctypes.data)
 
 
 class OracleScene:

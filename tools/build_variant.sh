@@ -9,6 +9,6 @@ mkdir -p build/variants
 /opt/rocm/bin/hipcc -std=c++17 -O3 -ffp-contract=off -fPIC --offload-arch=gfx950 -Wall -Wno-unused-function -Iinclude "$@" \
   -c ${WAVE_SRC:-$C/rt_kernel_wave.hip} -o build/variants/wave_$name.o
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o build/variants/librt_amd_$name.so \
-  $C/rt_host.o $C/rt_device.o $C/rt_kernel_lane.o $C/rt_queue.o $C/rt_gather.o build/variants/wave_$name.o -lz -ldl -pthread
+  $C/rt_host.o $C/rt_image.o $C/rt_device.o $C/rt_kernel_lane.o $C/rt_queue.o $C/rt_gather.o build/variants/wave_$name.o -lz -ldl -pthread
 rm -f build/variants/wave_$name.o
 echo build/variants/librt_amd_$name.so
