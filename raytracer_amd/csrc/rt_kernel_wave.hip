@@ -98,7 +98,6 @@ __device__ __forceinline__ uint64_t walk_asm(const float4* nodes, uint32_t varia
   uint32_t a_rem = rem | 0x100u, a_first = top_first, a_idx = 0u, a_rfirst = 0u, a_rmeta = 0u, a_k = 0u, a_res = 0u, a_prim = 0u, a_sp = 0u;
   uint64_t a_tmask = live, a_mine = live, a_live = live, a_acc = 0ull, a_und = 0ull, a_pass = 0ull, a_tp = 0ull, a_chg = 0ull;
   const uint64_t a_nodes = (uint64_t)(uintptr_t)nodes, a_tri = (uint64_t)(uintptr_t)tri_leaf;
-  const uint32_t a_sign = 0x80000000u;
   const float cmax = rt_max3(fabsf(fc.x), fabsf(fc.y), fabsf(fc.z));
   float a_det = 0.f, a_nb = 0.f, a_ng = 0.f, a_nt = 0.f;
   // (one copy of the block per kind of node test inside the one statement: sign-uniform rays (0), or the rays' common
@@ -110,7 +109,7 @@ __device__ __forceinline__ uint64_t walk_asm(const float4* nodes, uint32_t varia
           "+{s[20:21]}"(a_tp), "+{s22}"(a_k), "+{s[24:25]}"(a_chg), "+{s30}"(a_res), "+{s31}"(a_prim), "+{m0}"(a_sp),
           "+{v60}"(st.first), "+{v61}"(st.cur), "+{v62}"(st.mask_lo), "+{v63}"(st.mask_hi),
           "={v32}"(a_det), "={v33}"(a_nb), "={v35}"(a_ng), "={v36}"(a_nt)
-        : "{s[82:83]}"(a_nodes), "{s[92:93]}"(a_tri), "{s23}"(a_sign), "{s18}"(zpat), "{v[40:41]}"(e_xy), "{v42}"(e.z), "{v[44:45]}"(c_zx), "{v[46:47]}"(c_yz),
+        : "{s[82:83]}"(a_nodes), "{s[92:93]}"(a_tri), "{s18}"(zpat), "{v[40:41]}"(e_xy), "{v42}"(e.z), "{v[44:45]}"(c_zx), "{v[46:47]}"(c_yz),
           "{v[48:49]}"(c_yx), "{v50}"(inv.x), "{v51}"(inv.y), "{v52}"(inv.z), "{v53}"(fc.x), "{v54}"(fc.y), "{v55}"(fc.z), "{v56}"(cmax),
           "{v57}"(neg_eb), "{v58}"(hit.t), "{v59}"(stop_t)
         : "s36", "s37", "s38", "s39", "s40", "s41", "s42", "s43", "s44", "s45", "s46", "s47", "s48", "s49", "s50", "s51", "s52", "s53", "s54", "s55",

@@ -21,7 +21,6 @@ TRI = ("s92", "s93")
 ACC, UND, NR = "s[94:95]", "s[96:97]", "s[98:99]"
 TP = ("s20", "s21")              # next triangle record
 K = "s22"                        # triangles of the leaf still to test
-SIGN = "s23"                     # 0x80000000
 CHG, T64, PASS = "s[24:25]", "s[26:27]", "s[28:29]"
 RES, RPRIM = "s30", "s31"
 

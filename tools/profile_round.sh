@@ -11,6 +11,11 @@ bash tools/profile_headline.sh "$tag" > "$out/headline.log" 2>&1
 for sc in scenes/meshTransparentBunny.json scenes/lambertBPHSpheres.json scenes/meshMedBunny.json icosphere:6 icosphere:7; do
   timeout -k 10 200 python3 bench.py --scene "$sc" --no-cpu-baseline 2>> "$out/bench_scenes.log" | tail -1 >> "$out/bench_scenes.jsonl"
 done
+# what one GPU of N does per frame (the bands of rank 0 of N, exchange with a world of one): frames in flight, and one at a time
+: > "$out/band_shares.jsonl"
+for n in 2 4 8; do
+  RT_BENCH_SHARE_OF=$n timeout -k 10 200 python3 bench.py --steps 40 --warmup 5 --no-cpu-baseline 2>> "$out/bench_scenes.log" | tail -1 >> "$out/band_shares.jsonl"
+done
 bash tools/profile_scene.sh "${tag}_c5" meshTransparentBunny 3840x2160 3 > "$out/c5_profile.log" 2>&1
 f=$(find "gpurun_out/prof_${tag}_c5/trace" -name '*kernel_trace.csv' | head -1)
 python3 tools/frame_timeline.py "$f" > "$out/c5_frame_timeline.txt"
