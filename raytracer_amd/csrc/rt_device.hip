@@ -187,7 +187,7 @@ struct rt_dscene {
   RenderCtx ctx;
 };
 
-extern "C" const char* rt_version(void) { return "rt_amd 2.0 gfx950 (wave-synchronous traversal, exact division-free predicates)"; }
+extern "C" const char* rt_version(void) { return "rt_amd 2.2 gfx950 (wave-synchronous traversal in gfx950 assembly, exact division-free predicates)"; }
 
 extern "C" void rt_dscene_destroy(rt_dscene* d) {
   if (!d) return;
@@ -207,6 +207,8 @@ extern "C" int rt_scene_upload(const rt_scene* s, int device, rt_dscene** out) {
   DeviceGuard g(device);
   HIP_TRY(g.err);
   static_assert(sizeof(RtNode) == 32 && sizeof(RtWaveNode) == 32 && sizeof(RtTriGeom) == 48 && sizeof(RtTriShade) == 64 && sizeof(RtTriLeaf) == 64, "record sizes");
+  // (the walk addresses a leaf's triangle records by 32-bit byte offsets into their array)
+  if (s->tri_leaf.size() * sizeof(RtTriLeaf) >= (1ull << 32)) { rt_set_error("rt_scene_upload: more than 4 GiB of leaf triangle records"); return RT_ERR_LIMIT; }
   std::unique_ptr<rt_dscene> d(new rt_dscene());
   d->scene = std::make_shared<SceneArrays>();
   SceneArrays* A = d->scene.get();

@@ -95,8 +95,8 @@ __device__ __forceinline__ uint64_t walk_asm(const float4* nodes, uint32_t varia
   const RtVec3 c2 = {-d.x, -d.y, -d.z};                   // third column of the triangle solve (triangle.cu:118-120)
   const v2f e_xy = {e.x, e.y}, c_zx = {c2.z, c2.x}, c_yz = {c2.y, c2.z}, c_yx = {c2.y, c2.x};
   uint64_t a_blk = (uint64_t)(uintptr_t)(nodes + 2 * (size_t)top_first);
-  uint32_t a_rem = rem | 0x100u, a_first = top_first, a_idx = 0u, a_rfirst = 0u, a_rmeta = 0u, a_k = 0u, a_res = 0u, a_prim = 0u, a_sp = 0u;
-  uint64_t a_tmask = live, a_mine = live, a_live = live, a_acc = 0ull, a_und = 0ull, a_pass = 0ull, a_tp = 0ull, a_chg = 0ull;
+  uint32_t a_rem = rem | 0x100u, a_first = top_first, a_idx = 0u, a_rfirst = 0u, a_rmeta = 0u, a_tcur = 0u, a_tend = 0u, a_res = 0u, a_prim = 0u, a_sp = 0u;
+  uint64_t a_tmask = live, a_mine = live, a_live = live, a_acc = 0ull, a_und = 0ull, a_pass = 0ull, a_chg = 0ull;
   const uint64_t a_nodes = (uint64_t)(uintptr_t)nodes, a_tri = (uint64_t)(uintptr_t)tri_leaf;
   const float cmax = rt_max3(fabsf(fc.x), fabsf(fc.y), fabsf(fc.z));
   float a_det = 0.f, a_nb = 0.f, a_ng = 0.f, a_nt = 0.f;
@@ -106,7 +106,7 @@ __device__ __forceinline__ uint64_t walk_asm(const float4* nodes, uint32_t varia
     asm volatile(RT_TRACE_ASM
         : "+{s[68:69]}"(a_blk), "+{s70}"(a_rem), "+{s71}"(a_first), "+{s[72:73]}"(a_tmask), "+{s[74:75]}"(a_mine), "+{s[76:77]}"(a_live),
           "+{s78}"(a_idx), "+{s79}"(a_rfirst), "+{s80}"(a_rmeta), "+{s[94:95]}"(a_acc), "+{s[96:97]}"(a_und), "+{s[28:29]}"(a_pass),
-          "+{s[20:21]}"(a_tp), "+{s22}"(a_k), "+{s[24:25]}"(a_chg), "+{s30}"(a_res), "+{s31}"(a_prim), "+{m0}"(a_sp),
+          "+{s20}"(a_tcur), "+{s22}"(a_tend), "+{s[24:25]}"(a_chg), "+{s30}"(a_res), "+{s31}"(a_prim), "+{m0}"(a_sp),
           "+{v60}"(st.first), "+{v61}"(st.cur), "+{v62}"(st.mask_lo), "+{v63}"(st.mask_hi),
           "={v32}"(a_det), "={v33}"(a_nb), "={v35}"(a_ng), "={v36}"(a_nt)
         : "{s[82:83]}"(a_nodes), "{s[92:93]}"(a_tri), "{s18}"(zpat), "{v[40:41]}"(e_xy), "{v42}"(e.z), "{v[44:45]}"(c_zx), "{v[46:47]}"(c_yz),
@@ -114,7 +114,7 @@ __device__ __forceinline__ uint64_t walk_asm(const float4* nodes, uint32_t varia
           "{v57}"(neg_eb), "{v58}"(hit.t), "{v59}"(stop_t)
         : "s36", "s37", "s38", "s39", "s40", "s41", "s42", "s43", "s44", "s45", "s46", "s47", "s48", "s49", "s50", "s51", "s52", "s53", "s54", "s55",
           "s56", "s57", "s58", "s59", "s60", "s61", "s62", "s63", "s64", "s65", "s66", "s67", "s81", "s84", "s85", "s86", "s87", "s88", "s89", "s90",
-          "s91", "s98", "s99", "s26", "s27", "v34", "v37", "v38", "v39", "v64", "v65", "v66", "v67", "v68", "v69", "v70", "v71", "v72", "v73", "v74",
+          "s91", "s98", "s99", "s26", "s27", "s21", "v34", "v37", "v38", "v39", "v64", "v65", "v66", "v67", "v68", "v69", "v70", "v71", "v72", "v73", "v74",
           "v75", "v76", "v77", "v78", "v79", "vcc", "scc");
     if (a_res == 0u) break;
     if (a_res == 1u) {
@@ -281,7 +281,8 @@ __device__ __forceinline__ void trace_wave(const float4* __restrict__ nodes, int
     // never tested), s71 index of child 0, s[72:73] lanes that entered the branch, s[74:75] those of them still
     // undecided, s[76:77] undecided lanes of the wave, s78 child whose record is in s[84:91], s79/s80 links of the child
     // just tested, s81 byte offset, s[82:83] node array, s[92:93] triangle array, s[94:95] accepted lanes, s[96:97] undecided lanes,
-    // s[28:29] triangle candidates, s[20:21] next triangle record, s22 triangles left in the leaf, s[24:25] lanes
+    // s[28:29] triangle candidates, s20 / s21 byte offsets of the triangle record under test and the one behind it, s22 offset
+    // behind the leaf's last record, s[24:25] lanes
     // whose hit changed in the leaf, s30 reason / re-entry, s31 id of the candidate triangle; v[40:59] the ray
     // (origin, negated direction in the pairs the first stage multiplies, inverse direction, e * inv, margin terms,
     // closest hit so far, shadow-ray length), v[60:63] the wave's stack, v32 v33 v35 v36 determinant and numerators

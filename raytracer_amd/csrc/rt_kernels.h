@@ -230,7 +230,9 @@ void rt_launch_wave_kernel(const RtDeviceView& view, const RowMap& rows, bool bo
 // the same way are what the shared walk is good at): a counting sort on (direction octant, cell of the origin on a
 // 64^3 grid over the box around the origins themselves), all on the device - the number of rays is read from `state`.
 //   keys: one word per ray; bins: RT_QBINS words; sums: RT_QBIN_BLOCKS words; order: the sorted ray indices.
+#ifndef RT_QCELL_BITS
 #define RT_QCELL_BITS 6u
+#endif
 #define RT_QBINS (8u << (3u * RT_QCELL_BITS))
 #define RT_QBIN_BLOCK 1024u
 #define RT_QBIN_BLOCKS (RT_QBINS / RT_QBIN_BLOCK)

@@ -12,12 +12,14 @@ namespace {
 constexpr uint32_t QBLOCK = 256;
 constexpr uint32_t QGRID = 1024;   // 4 workgroups per compute unit
 
-__device__ __forceinline__ uint32_t spread3(uint32_t v) {   // 6 bits -> every third bit
-  v = (v | (v << 8)) & 0x0000300fu;
-  v = (v | (v << 4)) & 0x000030c3u;
-  v = (v | (v << 2)) & 0x00009249u;
+__device__ __forceinline__ uint32_t spread3(uint32_t v) {   // up to 9 bits -> every third bit
+  v = (v | (v << 16)) & 0x030000ffu;
+  v = (v | (v << 8)) & 0x0300f00fu;
+  v = (v | (v << 4)) & 0x030c30c3u;
+  v = (v | (v << 2)) & 0x09249249u;
   return v;
 }
+static_assert(RT_QCELL_BITS <= 9u, "spread3 handles nine bits");
 
 __device__ __forceinline__ uint32_t ray_count(const RtQState* state, uint32_t in_index, uint32_t queue_cap) {
   const uint32_t n = state->count[in_index];

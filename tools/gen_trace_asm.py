@@ -19,8 +19,10 @@ OFF = "s81"
 NX = 84                          # s[84:91]: node record
 TRI = ("s92", "s93")
 ACC, UND, NR = "s[94:95]", "s[96:97]", "s[98:99]"
-TP = ("s20", "s21")              # next triangle record
-K = "s22"                        # triangles of the leaf still to test
+# The triangle records of a leaf are addressed by their byte offset from the start of the record array (a scene's records stay
+# below 4 GiB: rt_device.hip checks): TCUR / TNXT take turns as "offset of the record under test" and "offset of the record
+# behind it, which is on its way", TEND is the offset behind the leaf's last record.
+TCUR, TNXT, TEND = "s20", "s21", "s22"
 CHG, T64, PASS = "s[24:25]", "s[26:27]", "s[28:29]"
 RES, RPRIM = "s30", "s31"
 
@@ -271,8 +273,9 @@ def scan_zero(pattern):
     return L
 
 
-def triangle(q, other, tag, next_off):
-    """The numerator stages on the record in s[q : q+15]; midway the record at TP + next_off is requested into s[other : other+15]."""
+def triangle(q, other, tag, cur, nxt):
+    """The numerator stages on the record in s[q : q+15] (at offset `cur`); midway the record behind it (offset `nxt` = `cur` + 64)
+    is requested into s[other : other+15]."""
     bxy, bz = "v[68:69]", "v74"
     bx, by = "v68", "v69"
     det, nb, nbs, ng, nt, sg = "v32", "v33", "v34", "v35", "v36", "v39"
@@ -290,7 +293,8 @@ def triangle(q, other, tag, next_off):
          "v_pk_mul_f32 v[78:79], %s, v[70:71]" % bxy,                                           # b.x m00 , b.y m10
          "v_add_f32 v76, v76, v77",
          "v_mul_f32 v77, %s, v75" % s(q + 6),                                                   # e1.z m20
-         "s_load_dwordx16 s[%d:%d], s[20:21], %s" % (other, other + 15, hex(next_off)),
+         "s_add_u32 %s, %s, 0x40" % (nxt, cur),
+         "s_load_dwordx16 s[%d:%d], s[%s:%s], %s" % (other, other + 15, TRI[0][1:], TRI[1][1:], nxt),
          "v_add_f32 %s, v76, v77" % det,
          "v_add_f32 v78, v78, v79",
          "v_mul_f32 v79, v75, %s" % bz,                                                         # m20 b.z
@@ -337,9 +341,7 @@ def triangle(q, other, tag, next_off):
          "s_cbranch_scc0 LT_end%s_%%=" % tag,
          # candidates: the quotients are formed outside; the walk goes on behind this record
          "s_mov_b32 %s, %s" % (RPRIM, s(q + 3)),
-         "s_add_u32 s20, s20, 0x40",
-         "s_addc_u32 s21, s21, 0",
-         "s_add_u32 %s, %s, -1" % (K, K),
+         "s_mov_b32 %s, %s" % (TCUR, nxt),                                                       # where the leaf goes on afterwards
          "s_mov_b32 %s, 2" % RES,
          "s_branch LT_out_%=",
          "LT_end%s_%%=:" % tag]
@@ -348,28 +350,21 @@ def triangle(q, other, tag, next_off):
 
 def leaf():
     L = ["LT_leaf_%=:",
-         "s_and_b32 %s, %s, 0xff" % (K, RMETA),
+         "s_and_b32 %s, %s, 0xff" % (TEND, RMETA),
          "s_cbranch_scc0 LT_next_%=",
-         "s_lshl_b32 %s, %s, 6" % (OFF, RFIRST),
-         "s_add_u32 s20, %s, %s" % (TRI[0], OFF),
-         "s_addc_u32 s21, %s, 0" % TRI[1],
+         "s_lshl_b32 %s, %s, 6" % (TCUR, RFIRST),
+         "s_lshl_b32 %s, %s, 6" % (TEND, TEND),
+         "s_add_u32 %s, %s, %s" % (TEND, TEND, TCUR),
          "s_mov_b64 %s, 0" % CHG,
          "LT_leaf_load_%=:",
          "s_waitcnt lgkmcnt(0)",
-         "s_load_dwordx16 s[%d:%d], s[20:21], 0x0" % (TA, TA + 15)]
-    L += triangle(TA, TB, "A", 0x40)
-    L += ["s_add_u32 %s, %s, -1" % (K, K),
-          "s_cmp_eq_u32 %s, 0" % K,
-          "s_cbranch_scc1 LT_leaf_done_%="]
-    # the record in TB sits at TP + 0x40: move TP there, so that both halves (and the exit to the quotients) see "TP = this record"
-    L += ["s_add_u32 s20, s20, 0x40",
-          "s_addc_u32 s21, s21, 0"]
-    L += triangle(TB, TA, "B", 0x40)
-    L += ["s_add_u32 s20, s20, 0x40",
-          "s_addc_u32 s21, s21, 0",
-          "s_add_u32 %s, %s, -1" % (K, K),
-          "s_cmp_eq_u32 %s, 0" % K,
-          "s_cbranch_scc0 LT_triA_%=",
+         "s_load_dwordx16 s[%d:%d], s[%s:%s], %s" % (TA, TA + 15, TRI[0][1:], TRI[1][1:], TCUR)]
+    L += triangle(TA, TB, "A", TCUR, TNXT)
+    L += ["s_cmp_lt_u32 %s, %s" % (TNXT, TEND),
+          "s_cbranch_scc0 LT_leaf_done_%="]
+    L += triangle(TB, TA, "B", TNXT, TCUR)
+    L += ["s_cmp_lt_u32 %s, %s" % (TCUR, TEND),
+          "s_cbranch_scc1 LT_triA_%=",
           "LT_leaf_done_%=:",
           "s_cmp_eq_u64 %s, 0" % CHG,
           "s_cbranch_scc1 LT_next_%=",
@@ -402,8 +397,8 @@ def block(pattern):
           "s_lshl_b32 %s, %s, 5" % (OFF, IDX),
           "s_load_dwordx8 s[84:91], %s, %s" % (BLK, OFF),
           "s_or_b64 %s, %s, %s" % (CHG, CHG, PASS),
-          "s_cmp_eq_u32 %s, 0" % K,
-          "s_cbranch_scc1 LT_leaf_done_%=",
+          "s_cmp_lt_u32 %s, %s" % (TCUR, TEND),
+          "s_cbranch_scc0 LT_leaf_done_%=",
           "s_branch LT_leaf_load_%=",
           "LT_exit_exact_%=:",
           "s_mov_b32 %s, 1" % RES,
@@ -416,7 +411,6 @@ def block(pattern):
 
 
 def main():
-    # (in both halves of the leaf loop TP names the record under test, so the exit to the quotients adds 0x40 in either)
     out = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "raytracer_amd", "csrc", "rt_trace_asm.inc")
     with open(out, "w") as f:
         f.write("// Generated by tools/gen_trace_asm.py - do not edit.  Register map and operands: rt_kernel_wave.hip (trace_wave).\n")
