@@ -330,6 +330,27 @@ def test_lights_parallel_to_axes_and_planes(tmp_path):
     _check_scene(str(p), 224, 136)
 
 
+def test_lights_with_direction_components_too_small_to_invert(tmp_path):
+    # Shadow rays with a direction component that is not zero but so small that 1 / d overflows (and one whose inverse is
+    # merely huge): the plane distances of the conservative node classification cannot be formed for them, every node test
+    # of such a ray has to come from the exact, division-free form.  A mirror variant sends the same rays through the walk
+    # of the kernels with bounce rays.
+    lights = '''
+    {"__type__": "directional_light", "direction": [1e-40, -1, 0], "color": [0.3, 0.2, 0.2]},
+    {"__type__": "directional_light", "direction": [0, -1, -3e-39], "color": [0.2, 0.3, 0.2]},
+    {"__type__": "directional_light", "direction": [2e-39, -1, 4e-41], "color": [0.2, 0.2, 0.3]},
+    {"__type__": "directional_light", "direction": [1e-30, -1, -1e-33], "color": [0.1, 0.1, 0.1]},
+    {"__type__": "ambient_light", "color": [0.1, 0.1, 0.1]}'''
+    import re
+    scene = re.sub(r'"lights": \[.*?\n  \],', lambda m: '"lights": [' + lights + "\n  ],", PARALLEL_LIGHTS_SCENE, flags=re.S)
+    p = tmp_path / "tiny_components.json"
+    p.write_text(scene)
+    _check_scene(str(p), 224, 136)
+    q = tmp_path / "tiny_components_mirror.json"
+    q.write_text(scene.replace('["white_lambert"]', '["white_lambert", "gray_mirror"]'))
+    _check_scene(str(q), 160, 96)
+
+
 @pytest.mark.parametrize("k,w,h", [(3, 256, 256), (5, 320, 180)])
 def test_synthetic_icosphere_scene(tmp_path, k, w, h):
     # The benchmark's synthetic mesh (20 * 4**k triangles over the large plane), at sizes the oracle renders in seconds.
