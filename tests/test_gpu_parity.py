@@ -167,11 +167,12 @@ def test_dragon_4k_ray_count_and_band_parity():
     assert frac_ok >= 0.999, (frac_ok, n_diff, max_diff)
 
 
+@pytest.mark.parametrize("scene", ["meshMedBunny", "meshTransparentBunny"])   # (the second: bounce rays from queues, pixels named by their place in the band buffer)
 @pytest.mark.parametrize("nranks", [1, 2, 3, 8])
-def test_band_partition_reproduces_the_full_image(nranks):
+def test_band_partition_reproduces_the_full_image(nranks, scene):
     import torch
     w, h = 200, 150   # 10 bands of 16 rows, the last one ragged
-    ds = rt.DeviceScene(rt.Scene("scenes/meshMedBunny.json", w, h, 3))
+    ds = rt.DeviceScene(rt.Scene("scenes/%s.json" % scene, w, h, 3))
     full, fids, _, fst = ds.render_host()
     tiles, id_tiles, rays = [], [], 0
     nb_max = ds.band_count(16, 0, nranks)
