@@ -802,6 +802,10 @@ enum { PH_CLOSEST = 0, PH_SHADOW = 1, PH_DONE = 2, PH_SHADE = 3 };
 #ifndef RT_WAVES_PER_SIMD
 #define RT_WAVES_PER_SIMD 5
 #endif
+#ifndef RT_WAVES_PER_SIMD_QPRIMARY
+#define RT_WAVES_PER_SIMD_QPRIMARY 4   // (glass bunny 4K: 5.18 ms at five waves, 5.11 at four: the dielectric shading code wants the registers)
+#endif
+#define RT_WAVES_PER_SIMD_QPRIMARY_OR_PLAIN(q) ((q) ? RT_WAVES_PER_SIMD_QPRIMARY : RT_WAVES_PER_SIMD)
 
 // Shading state of a lane.  It is dead while the wave traverses the octree, and the traversal is where
 // the registers are needed, so it is parked in LDS ([word][thread], conflict-free) around every trace.
@@ -820,7 +824,6 @@ struct ShadeState {
     return i == 0 ? a : (i == 1 ? b : c);
   }
   __device__ __forceinline__ void set_level(int i, float v) { level0 = i == 0 ? v : level0; level1 = i == 1 ? v : level1; level2 = i == 2 ? v : level2; }
-  static constexpr int WORDS = BOUNCE ? 30 : 19;   // (without bounce rays the pixel's colour is not carried: its one ray finishes it)
 };
 
 // One statement per word (no temporary array: the state has to stay in registers on both sides).
@@ -829,25 +832,33 @@ struct ShadeState {
 #define RT_SHADE_INTS(X) X(13, mfirst) X(14, mcount) X(15, mi) X(16, li) X(17, vis_known) X(18, vis_occluded)
 #define RT_SHADE_BOUNCE_FLOATS(X) X(19, att.x) X(20, att.y) X(21, att.z) X(22, level0) X(23, level1) X(24, level2) X(25, color.x) X(26, color.y) X(27, color.z)
 #define RT_SHADE_BOUNCE_INTS(X) X(28, nlevel) X(29, depth)
-template <bool BOUNCE, bool TEX>
+// QPRIMARY (the primary-ray pass of a frame whose bounce rays go to queues): of the bounce words only the refraction
+// levels are kept (a dielectric hit writes them, the hit's further materials read them); attenuation, depth and level
+// count are those of a primary ray throughout, and the pixel's colour is finished by its one ray or by the term slots.
+template <bool BOUNCE, bool QPRIMARY> struct ParkedWords { static constexpr int N = !BOUNCE ? 19 : (QPRIMARY ? 22 : 30); };
+template <bool BOUNCE, bool TEX, bool QPRIMARY>
 __device__ __forceinline__ void park(const ShadeState<BOUNCE>& s, float* lds) {
   uint32_t* ldu = (uint32_t*)lds;
+  constexpr int N = ParkedWords<BOUNCE, QPRIMARY>::N;
 #define PUT_F(k, f) lds[(k) * RT_WBLOCK] = s.f;
 #define PUT_I(k, f) ldu[(k) * RT_WBLOCK] = (uint32_t)s.f;
   RT_SHADE_FLOATS(PUT_F) RT_SHADE_INTS(PUT_I)
-  if (BOUNCE) { RT_SHADE_BOUNCE_FLOATS(PUT_F) RT_SHADE_BOUNCE_INTS(PUT_I) }
-  if (TEX) { PUT_F(ShadeState<BOUNCE>::WORDS, tu) PUT_F(ShadeState<BOUNCE>::WORDS + 1, tv) }
+  if (BOUNCE && !QPRIMARY) { RT_SHADE_BOUNCE_FLOATS(PUT_F) RT_SHADE_BOUNCE_INTS(PUT_I) }
+  if (BOUNCE && QPRIMARY) { PUT_F(19, level0) PUT_F(20, level1) PUT_F(21, level2) }
+  if (TEX) { PUT_F(N, tu) PUT_F(N + 1, tv) }
 #undef PUT_F
 #undef PUT_I
 }
-template <bool BOUNCE, bool TEX>
+template <bool BOUNCE, bool TEX, bool QPRIMARY>
 __device__ __forceinline__ void unpark(ShadeState<BOUNCE>& s, const float* lds) {
   const uint32_t* ldu = (const uint32_t*)lds;
+  constexpr int N = ParkedWords<BOUNCE, QPRIMARY>::N;
 #define GET_F(k, f) s.f = lds[(k) * RT_WBLOCK];
 #define GET_I(k, f) s.f = (decltype(s.f))ldu[(k) * RT_WBLOCK];
   RT_SHADE_FLOATS(GET_F) RT_SHADE_INTS(GET_I)
-  if (BOUNCE) { RT_SHADE_BOUNCE_FLOATS(GET_F) RT_SHADE_BOUNCE_INTS(GET_I) }
-  if (TEX) { GET_F(ShadeState<BOUNCE>::WORDS, tu) GET_F(ShadeState<BOUNCE>::WORDS + 1, tv) }
+  if (BOUNCE && !QPRIMARY) { RT_SHADE_BOUNCE_FLOATS(GET_F) RT_SHADE_BOUNCE_INTS(GET_I) }
+  if (BOUNCE && QPRIMARY) { GET_F(19, level0) GET_F(20, level1) GET_F(21, level2) s.att = {1.f, 1.f, 1.f}; s.nlevel = 0; s.depth = 0; }
+  if (TEX) { GET_F(N, tu) GET_F(N + 1, tv) }
 #undef GET_F
 #undef GET_I
 }
@@ -901,8 +912,9 @@ __device__ __forceinline__ T late_struct(size_t offset) {
 // (1920x1080: 1.24 -> 1.28 ms) nor where shading weighs (sphere scenes: + 50 %); the launch chooses.
 // TEX: the scene has texture materials (two more words of shading state, a texel fetch per material and light: variants
 // of their own, so that every other scene runs the kernels it ran before).
-template <bool BOUNCE, bool COUNT, bool QUEUES, bool DENSE = false, bool TEX = false>
-__global__ __launch_bounds__(RT_WBLOCK, BOUNCE ? RT_WAVES_PER_SIMD_BOUNCE : (DENSE ? RT_WAVES_PER_SIMD + 1 : RT_WAVES_PER_SIMD)) void render_wave(
+// QPRIMARY (with QUEUES): the launch casts the primary rays; without it a QUEUES launch renders a queue.
+template <bool BOUNCE, bool COUNT, bool QUEUES, bool DENSE = false, bool TEX = false, bool QPRIMARY = false>
+__global__ __launch_bounds__(RT_WBLOCK, (BOUNCE && !QPRIMARY) ? RT_WAVES_PER_SIMD_BOUNCE : (DENSE ? RT_WAVES_PER_SIMD + 1 : RT_WAVES_PER_SIMD_QPRIMARY_OR_PLAIN(QPRIMARY))) void render_wave(
     const float4* __restrict__ nodes, const float4* __restrict__ tri_leaf, const RtWaveArgs A) {
   const RtSphere* __restrict__ spheres = A.spheres;
   const int n_spheres = A.n_spheres, has_oct = A.has_oct, n_wnodes = A.n_wnodes;
@@ -913,7 +925,7 @@ __global__ __launch_bounds__(RT_WBLOCK, BOUNCE ? RT_WAVES_PER_SIMD_BOUNCE : (DEN
   // The counters and the finished colour only ever live there: they are touched a few times per pixel, and as values that
   // every round of the main loop carries along they cost six registers (in the six-wave variant: six spill stores per
   // round) for nothing.
-  constexpr int SW = ShadeState<BOUNCE>::WORDS + (TEX ? 2 : 0);   // words of parked shading state
+  constexpr int SW = ParkedWords<BOUNCE, QPRIMARY>::N + (TEX ? 2 : 0);   // words of parked shading state
   __shared__ float parked[(SW + 6) * RT_WBLOCK];
   uint32_t (*pack)[48] = (uint32_t (*)[48])parked;   // [wave][48]
   // The thread's index within its workgroup.  It is handed over in a register at the start and cannot be asked for again;
@@ -994,16 +1006,16 @@ __global__ __launch_bounds__(RT_WBLOCK, BOUNCE ? RT_WAVES_PER_SIMD_BOUNCE : (DEN
   RtVec3 tr_e, tr_d;        // ray being traced
   float tr_stop = -1.f;     // >= 0: shadow ray, length to the light
   int phase;
-  const bool wavefront = BOUNCE && QUEUES;                    // bounce rays leave through the queue
+  constexpr bool wavefront = BOUNCE && QUEUES;                // bounce rays leave through the queue
   // every ray through the assembly walk, class by class (trace_class)?  The variants with bounce rays keep the general
   // walk for their mixed waves (measured with all variants class by class: glass bunny 1920x1080 3.23 -> 3.55 ms, 4K and
   // the mirror scenes within 1 %).
 #ifdef RT_NO_ASM_WALK
   constexpr bool CLASSES = false;
 #else
-  constexpr bool CLASSES = !BOUNCE && !COUNT && !RT_PATHS_ON;
+  constexpr bool CLASSES = (!BOUNCE || QPRIMARY) && !COUNT && !RT_PATHS_ON;
 #endif
-  const bool queued = BOUNCE && QUEUES && A.wf.in != nullptr;   // this launch renders a queue of bounce rays, one per lane
+  constexpr bool queued = wavefront && !QPRIMARY;   // this launch renders a queue of bounce rays, one per lane
   if (!queued) {
     const Pixel px0 = pixel_of(TID());
     phase = px0.valid ? PH_CLOSEST : PH_DONE;
@@ -1102,7 +1114,7 @@ __global__ __launch_bounds__(RT_WBLOCK, BOUNCE ? RT_WAVES_PER_SIMD_BOUNCE : (DEN
       const bool want = phase != PH_DONE;
       // the instrumented variant walks shadow rays to the end, as the reference does, so that its test counts match
       const float stop_t = (phase == PH_SHADOW && !COUNT) ? tr_stop : -1.f;
-      park<BOUNCE, TEX>(sh, MY_PARK());
+      park<BOUNCE, TEX, QPRIMARY>(sh, MY_PARK());
       asm volatile("" ::: "memory");
       if (CLASSES) {
         float* const bary = parked + (SW + 4) * RT_WBLOCK + (RT_WBLOCK == 64 ? 0 : (TID() & ~63));   // the wave's columns of the two barycentric words
@@ -1112,7 +1124,7 @@ __global__ __launch_bounds__(RT_WBLOCK, BOUNCE ? RT_WAVES_PER_SIMD_BOUNCE : (DEN
       }
       else trace_wave<COUNT>(nodes, n_wnodes, tri_leaf, spheres, n_spheres, has_oct != 0, want, tr_e, tr_d, stop_t, h, st, LANE(), tl, cull_sh + 16 * (TID() >> 6));
       asm volatile("" ::: "memory");
-      unpark<BOUNCE, TEX>(sh, MY_PARK());
+      unpark<BOUNCE, TEX, QPRIMARY>(sh, MY_PARK());
     }
     if (traced) count(N_TRACED);
     const rt_kernarg_ptr ka = late_args();   // one opaque copy for the whole shading phase: its loads go out together
@@ -1161,7 +1173,7 @@ __global__ __launch_bounds__(RT_WBLOCK, BOUNCE ? RT_WAVES_PER_SIMD_BOUNCE : (DEN
             phase = PH_DONE;
             break;
           }
-          if (!BOUNCE) {   // the pixel's only ray: its bytes wait in LDS for the end of the wave
+          if (!BOUNCE || QPRIMARY) {   // the pixel's only ray: its bytes wait in LDS for the end of the wave
             const float cx = 0.f + sh.att.x * sh.colr.x, cy = 0.f + sh.att.y * sh.colr.y, cz = 0.f + sh.att.z * sh.colr.z;
             MY_COUNTS()[3 * RT_WBLOCK] = (uint32_t)rt_quantise(cx) | ((uint32_t)rt_quantise(cy) << 8) | ((uint32_t)rt_quantise(cz) << 16);
             phase = PH_DONE;
@@ -1288,7 +1300,7 @@ __global__ __launch_bounds__(RT_WBLOCK, BOUNCE ? RT_WAVES_PER_SIMD_BOUNCE : (DEN
   // (Pixels whose rays went through the queues are written again, with their sum, by the resolve kernel.)
   if (!queued) {
     uint8_t q[3];
-    if (BOUNCE) { q[0] = rt_quantise(sh.color.x); q[1] = rt_quantise(sh.color.y); q[2] = rt_quantise(sh.color.z); }
+    if (BOUNCE && !QPRIMARY) { q[0] = rt_quantise(sh.color.x); q[1] = rt_quantise(sh.color.y); q[2] = rt_quantise(sh.color.z); }
     else {
       asm volatile("" ::: "memory");
       const uint32_t packed = MY_COUNTS()[3 * RT_WBLOCK];   // (0 for a lane without a pixel: the bytes of colour 0)
@@ -1392,6 +1404,10 @@ void rt_launch_wave_kernel(const RtDeviceView& V, const RowMap& rows, bool bounc
 #define LAUNCH_TEX(B, C) hipLaunchKernelGGL((render_wave<B, C, false, false, true>), grid, block, 0, stream, V.wnodes, V.tri_leaf, A)
     if (bounce && count) LAUNCH_TEX(true, true); else if (bounce) LAUNCH_TEX(true, false); else if (count) LAUNCH_TEX(false, true); else LAUNCH_TEX(false, false);
 #undef LAUNCH_TEX
+  }
+  else if (wf.enabled && !wf.in) {   // the primary-ray pass of a frame rendered from queues
+    if (count) hipLaunchKernelGGL((render_wave<true, true, true, false, false, true>), grid, block, 0, stream, V.wnodes, V.tri_leaf, A);
+    else hipLaunchKernelGGL((render_wave<true, false, true, false, false, true>), grid, block, 0, stream, V.wnodes, V.tri_leaf, A);
   }
   else if (wf.enabled) { if (count) LAUNCH(true, true, true); else LAUNCH(true, false, true); }
   else if (bounce && count) LAUNCH(true, true, false);
