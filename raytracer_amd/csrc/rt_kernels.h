@@ -227,8 +227,11 @@ void rt_launch_lane_kernel(const RtDeviceView& view, const RowMap& rows, bool bo
 void rt_launch_wave_kernel(const RtDeviceView& view, const RowMap& rows, bool bounce, bool count, uint8_t* rgb, int32_t* ids,
                            float* ts, unsigned long long* counters, bool tally, const RtQueues& wf, hipStream_t stream);
 // Coherence order of a queue's rays (any order gives the same image; waves of rays that start close together and head
-// the same way are what the shared walk is good at): a counting sort on (direction octant, cell of the origin on a
-// 64^3 grid over the box around the origins themselves), all on the device - the number of rays is read from `state`.
+// the same way are what the shared walk is good at): a counting sort on (direction class, cell of the origin on a grid
+// over the box around the origins themselves), all on the device - the number of rays is read from `state`.
+//   dir_grid > 0: the class is the face of the cube around the origin that the ray leaves through and a dir_grid x dir_grid
+//   cell on it (dir_grid even: the rays of a class agree on their signs), the grid has 2^cell_bits cells a side;
+//   dir_grid == 0: the class is the direction's octant, the grid 64^3, the octant leading from octant_first_min rays on.
 //   keys: one word per ray; bins: RT_QBINS words; sums: RT_QBIN_BLOCKS words; order: the sorted ray indices.
 #ifndef RT_QCELL_BITS
 #define RT_QCELL_BITS 6u
@@ -236,7 +239,7 @@ void rt_launch_wave_kernel(const RtDeviceView& view, const RowMap& rows, bool bo
 #define RT_QBINS (8u << (3u * RT_QCELL_BITS))
 #define RT_QBIN_BLOCK 1024u
 #define RT_QBIN_BLOCKS (RT_QBINS / RT_QBIN_BLOCK)
-void rt_launch_ray_order(const RtQRay* rays, RtQState* state, uint32_t in_index, uint32_t queue_cap, uint32_t octant_first_min,
+void rt_launch_ray_order(const RtQRay* rays, RtQState* state, uint32_t in_index, uint32_t queue_cap, uint32_t octant_first_min, uint32_t dir_grid, uint32_t cell_bits,
                          uint32_t* keys, uint32_t* bins, uint32_t* sums, uint32_t* order, hipStream_t stream);
 // Between two generations: the queue that was just rendered becomes the next output queue (its count is cleared), the
 // box around the origins is emptied.

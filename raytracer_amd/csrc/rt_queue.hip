@@ -85,7 +85,7 @@ __global__ __launch_bounds__(QBLOCK) void q_bounds(const RtQRay* __restrict__ ra
 
 // Pass 1: the key of every ray, and how many rays each key has.
 __global__ __launch_bounds__(QBLOCK) void q_keys(const RtQRay* __restrict__ rays, const RtQState* __restrict__ state, uint32_t in_index, uint32_t queue_cap, uint32_t octant_first_min,
-                                                 uint32_t* __restrict__ keys, uint32_t* __restrict__ bins) {
+                                                 uint32_t dir_grid, uint32_t cell_bits, uint32_t* __restrict__ keys, uint32_t* __restrict__ bins) {
   const uint32_t n = ray_count(state, in_index, queue_cap);
   if (n < RT_QUEUE_SORT_MIN) return;
   float box_lo[3], inv_cell[3];
@@ -95,7 +95,7 @@ __global__ __launch_bounds__(QBLOCK) void q_keys(const RtQRay* __restrict__ rays
     if (a < b) {
       box_lo[k] = unordered(a);
       const float side = unordered(b) - box_lo[k];
-      if (side > 0.f && side - side == 0.f) inv_cell[k] = (float)(1u << RT_QCELL_BITS) / side;
+      if (side > 0.f && side - side == 0.f) inv_cell[k] = (float)(1u << (dir_grid ? cell_bits : RT_QCELL_BITS)) / side;
     }
   }
   // with a million rays a generation grouping by octant first gives the better waves, with fewer grouping by origin first
@@ -111,12 +111,25 @@ __global__ __launch_bounds__(QBLOCK) void q_keys(const RtQRay* __restrict__ rays
       uint32_t cell[3];
       for (int k = 0; k < 3; k++) {
         const float g = (q.e[k] - box_lo[k]) * inv_cell[k];
-        const float top = (float)((1u << RT_QCELL_BITS) - 1u);
+        const float top = (float)((1u << (dir_grid ? cell_bits : RT_QCELL_BITS)) - 1u);
         cell[k] = g > 0.f ? (g < top ? (uint32_t)g : (uint32_t)top) : 0u;   // (NaN -> 0)
       }
       const uint32_t oct = (q.d[0] < 0.f ? 1u : 0u) | (q.d[1] < 0.f ? 2u : 0u) | (q.d[2] < 0.f ? 4u : 0u);
       const uint32_t morton = spread3(cell[0]) | (spread3(cell[1]) << 1) | (spread3(cell[2]) << 2);
       key = octant_first ? ((oct << (3u * RT_QCELL_BITS)) | morton) : ((morton << 3) | oct);
+      if (dir_grid) {
+        // direction first, finely: the face of the cube around the origin that the ray leaves through and a dir_grid x dir_grid
+        // grid on that face whose lines include the face's axes, so that the rays of a bin agree on their signs; then the cell
+        const float ad[3] = {fabsf(q.d[0]), fabsf(q.d[1]), fabsf(q.d[2])};
+        const int ax = (ad[0] >= ad[1] && ad[0] >= ad[2]) ? 0 : (ad[1] >= ad[2] ? 1 : 2);
+        const float inv_major = ad[ax] > 0.f ? 1.f / ad[ax] : 0.f;
+        const float u = q.d[(ax + 1) % 3] * inv_major, v = q.d[(ax + 2) % 3] * inv_major;   // in [-1, 1]
+        const float half = 0.5f * (float)dir_grid;
+        int ub = (int)((u + 1.f) * half), vb = (int)((v + 1.f) * half);
+        ub = ub < 0 ? 0 : (ub >= (int)dir_grid ? (int)dir_grid - 1 : ub); vb = vb < 0 ? 0 : (vb >= (int)dir_grid ? (int)dir_grid - 1 : vb);
+        const uint32_t face = (uint32_t)ax * 2u + (q.d[ax] < 0.f ? 1u : 0u);
+        key = (((face * dir_grid + (uint32_t)ub) * dir_grid + (uint32_t)vb) << (3u * cell_bits)) | morton;
+      }
       keys[i] = key;
     }
     grouped_add(bins, key, active, false);
@@ -225,11 +238,11 @@ __global__ __launch_bounds__(QBLOCK) void q_resolve(const RtQState* __restrict__
 
 }  // namespace
 
-void rt_launch_ray_order(const RtQRay* rays, RtQState* state, uint32_t in_index, uint32_t queue_cap, uint32_t octant_first_min,
+void rt_launch_ray_order(const RtQRay* rays, RtQState* state, uint32_t in_index, uint32_t queue_cap, uint32_t octant_first_min, uint32_t dir_grid, uint32_t cell_bits,
                          uint32_t* keys, uint32_t* bins, uint32_t* sums, uint32_t* order, hipStream_t stream) {
   hipLaunchKernelGGL(q_bounds, dim3(BGRID), dim3(QBLOCK), 0, stream, rays, state, in_index, queue_cap);
   (void)hipMemsetAsync(bins, 0, (size_t)RT_QBINS * sizeof(uint32_t), stream);
-  hipLaunchKernelGGL(q_keys, dim3(QGRID), dim3(QBLOCK), 0, stream, rays, (const RtQState*)state, in_index, queue_cap, octant_first_min, keys, bins);
+  hipLaunchKernelGGL(q_keys, dim3(QGRID), dim3(QBLOCK), 0, stream, rays, (const RtQState*)state, in_index, queue_cap, octant_first_min, dir_grid, cell_bits, keys, bins);
   hipLaunchKernelGGL(q_scan_blocks, dim3(RT_QBIN_BLOCKS), dim3(QBLOCK), 0, stream, bins, sums);
   hipLaunchKernelGGL(q_scan_sums, dim3(1), dim3(1024), 0, stream, sums);
   hipLaunchKernelGGL(q_scan_bins, dim3(RT_QBIN_BLOCKS), dim3(QBLOCK), 0, stream, bins, sums);
