@@ -217,7 +217,7 @@ extern "C" int rt_scene_upload(const rt_scene* s, int device, rt_dscene** out) {
   V.cam = s->cam;
   int rc;
 #define UP(field, vec) if ((rc = upload(A, vec, (const void**)&V.field)) != RT_OK) return rc;
-  UP(nodes, s->nodes) UP(wnodes, s->wnodes) UP(leaf_refs, s->leaf_refs) UP(tri_geom, s->tri_geom) UP(tri_leaf, s->tri_leaf) UP(tri_shade, s->tri_shade)
+  UP(nodes, s->nodes) UP(wnodes, s->wnodes) UP(node_skip, s->node_skip) UP(leaf_refs, s->leaf_refs) UP(tri_geom, s->tri_geom) UP(tri_leaf, s->tri_leaf) UP(tri_shade, s->tri_shade)
   UP(spheres, s->spheres) UP(lights, s->lights) UP(materials, s->materials) UP(mat_index, s->mat_index)
   UP(mesh_mat_first, s->mesh_mat_first) UP(mesh_mat_count, s->mesh_mat_count)
   if (!s->textures.empty()) { UP(tri_uv, s->tri_uv) UP(textures, s->textures) UP(texels, s->texels) }   // only scenes with texture materials

@@ -785,6 +785,30 @@ void load_scene_into(rt_scene& sc, const std::string& scene_path, const std::str
       t.ny = -g.e1[0] * g.e2[2] + g.e1[2] * g.e2[0];
       t.nz = g.e1[0] * g.e2[1] - g.e1[1] * g.e2[0];
     }
+    // The walk visits children in the fixed order 0..7 whatever the ray, so "what comes after this subtree" is a property of
+    // the node: its next sibling that is not an empty leaf, else what comes after its parent.  With that link per node a
+    // ray can be walked without a stack (rt_kernel_wave.hip, trace_lanes): accepted branch -> its first child that is not
+    // an empty leaf; anything else -> the link.  0xffffffff ends the walk.
+    sc.node_skip.assign(sc.nodes.size() + 1, 0xffffffffu);
+    {
+      struct Threader {
+        rt_scene& sc;
+        void run(int32_t node, uint32_t after) {
+          sc.node_skip[node] = after;
+          int32_t first, count;
+          memcpy(&first, &sc.nodes[node].a[3], 4); memcpy(&count, &sc.nodes[node].b[3], 4);
+          if (count >= 0) return;
+          uint32_t next = after;
+          for (int c = 7; c >= 0; c--) {
+            int32_t cc; memcpy(&cc, &sc.nodes[first + c].b[3], 4);
+            if (cc == 0) continue;   // an empty leaf is never visited
+            run(first + c, next);
+            next = (uint32_t)(first + c);
+          }
+        }
+      } threader{sc};
+      threader.run(0, 0xffffffffu);
+    }
     sc.nodes.push_back(RtNode{});   // pad; not counted in info.n_nodes
     sc.wnodes.assign(sc.nodes.size() * RT_NODE_VARIANTS, RtWaveNode{});
     std::vector<uint8_t> sibling(sc.nodes.size(), 0);   // position of a record among the eight children of its parent

@@ -98,6 +98,7 @@ struct rt_scene {
   std::vector<int32_t> mesh_mat_first, mesh_mat_count;
   std::vector<RtNode> nodes;                      // nodes[0] = root (always a branch) when non-empty
   std::vector<RtWaveNode> wnodes;                 // nodes in the wave kernel's layout: RT_NODE_VARIANTS copies of nodes.size() records
+  std::vector<uint32_t> node_skip;                // per node: where a walk in the fixed child order goes when it is done with the node's subtree (see rt_host.cpp)
   std::vector<int32_t> leaf_refs;
   std::vector<RtTriGeom> tri_geom;
   std::vector<RtTriLeaf> tri_leaf;                // intersection records repeated in leaf order (index space of leaf_refs), plus one pad record

@@ -794,6 +794,73 @@ __device__ __forceinline__ uint64_t trace_class(const float4* __restrict__ nodes
   return cls;
 }
 
+// Closest hit with every lane walking its OWN ray (measurement builds only, -DRT_LANE_WALK: see render_wave for what it
+// measured).  The idea: for rays that have little in common (a queue of bounce rays that scatter inside a mesh) the
+// shared walk costs the union of the 64 subtrees per wave; here the lanes walk side by side, each with its own node and
+// triangle loads.  No stack: the reference visits children in the fixed order 0..7 whatever the ray, so where a walk
+// goes when it is done with a node's subtree is a property of the node (RtDeviceView::node_skip, built by the host) -
+// an accepted branch leads to its first child that is not an empty leaf, everything else to the link.  A lane is either
+// at a node or inside a leaf's triangle run; one round of the loop takes every lane one step (a node test or a triangle
+// test), with the lane's own running closest t, so the decisions are those of the lane's own depth-first walk in the
+// reference's order.  The predicates are the ones the shared walk uses in compiled form (rt_math.h: conservative slab
+// classification, exact score / compare form where it abstains, numerators + quotients for triangles).
+__device__ __forceinline__ void trace_lanes(const float4* __restrict__ nodes, const uint32_t* __restrict__ node_skip, const float4* __restrict__ tri_leaf,
+                                            const RtSphere* __restrict__ spheres, int n_spheres, bool has_oct, bool want,
+                                            const RtVec3& e, const RtVec3& d, float stop_t, Hit& hit) {
+  constexpr uint32_t END = 0xffffffffu;
+  bool live = want;   // (a shadow ray leaves as soon as it is known to be blocked)
+  if (has_oct) {
+    const RtVec3 inv = {1.f / d.x, 1.f / d.y, 1.f / d.z};   // only feeds the conservative classification
+    const bool zx = d.x == 0.f, zy = d.y == 0.f, zz = d.z == 0.f, any_zero = zx | zy | zz;
+    uint32_t node = END, tri = 0u, tri_end = 0u;   // the lane is inside a leaf while tri < tri_end
+    {   // the root is entered without a test (ray.cu:36-38)
+      const float4 root_b = nodes[1];
+      const uint32_t first = __float_as_uint(root_b.z), occupied = __float_as_uint(root_b.w) & 0xffu;
+      if (want && occupied) node = first + (uint32_t)__builtin_ctz(occupied);
+    }
+    while (__builtin_amdgcn_ballot_w64(node != END || tri < tri_end)) {
+      if (tri < tri_end) {   // one triangle of the leaf (octtree.cu:264-274: all of them, in insertion order)
+        const float4* q = tri_leaf + 4 * (size_t)tri;
+        const float4 q0 = q[0], q1 = q[1], q2 = q[2];
+        const RtTriNum n = rt_triangle_numerators({q0.x, q0.y, q0.z}, {q1.x, q1.y, q1.z}, {q2.x, q2.y, q2.w}, e, d);
+        tri++;
+        float t, bet, gam;
+        if (rt_triangle_candidate(n) && rt_triangle_finish(n, hit.t, t, bet, gam)) {
+          hit.t = t; hit.prim = (int32_t)__float_as_uint(q0.w); hit.bet = bet; hit.gam = gam;
+          if (stop_t >= 0.f && t < stop_t) { live = false; node = END; tri = tri_end; }   // ray.cu:70 only asks whether something is closer than the light
+        }
+      } else if (node != END) {
+        const float4 a = nodes[2 * (size_t)node], b = nodes[2 * (size_t)node + 1];
+        const uint32_t after = node_skip[node];
+        const RtVec3 lo = {a.x, a.z, b.x}, hi = {a.y, a.w, b.y};
+        const int cls = rt_node_slab_class(lo, hi, e, inv, hit.t, any_zero, zx, zy, zz);
+        bool accepted = cls > 0;
+        if (cls == 0) {   // within rounding of a boundary: the exact form decides (octtree.cu:276-321)
+          const RtRayConst rc = rt_ray_const(d);
+          const RtVec3 ini = {lo.x, lo.y, hi.z}, end = {hi.x, hi.y, lo.z};
+          const float S = rt_node_score(ini, end, e, d, rc, rt_t_float(rc, hit.t));
+          accepted = S > 0.f;
+          if (S == 0.f) accepted = rt_node_accept_exact(ini, end, e, d, rc, rt_t_const(rc, hit.t));
+        }
+        const uint32_t first = __float_as_uint(b.z), meta = __float_as_uint(b.w);
+        node = after;
+        if (accepted) {
+          if (meta & 0x80000000u) { const uint32_t occupied = meta & 0xffu; if (occupied) node = first + (uint32_t)__builtin_ctz(occupied); }
+          else { tri = first; tri_end = first + (meta & 0xffu); }   // a leaf: its triangles, then on to `after`
+        }
+      }
+    }
+  }
+  if (n_spheres > 0) {
+    for (int32_t s = 0; s < n_spheres; s++) {   // ray.cu:52-53
+      if (live && rt_sphere_test(ld3(spheres[s].c), spheres[s].r, e, d, hit.t)) {
+        hit.prim = -2 - s;
+        if (stop_t >= 0.f && hit.t < stop_t) live = false;
+      }
+    }
+  }
+}
+
 enum { PH_CLOSEST = 0, PH_SHADOW = 1, PH_DONE = 2, PH_SHADE = 3 };
 
 #ifndef RT_WAVES_PER_SIMD_BOUNCE
@@ -877,6 +944,7 @@ struct RtWaveArgs {
   const RtSphere* spheres; const RtLight* lights; const RtMaterial* materials; const int32_t* mat_index;
   const int32_t* mesh_mat_first; const int32_t* mesh_mat_count;
   const float* tri_uv; const RtTexture* textures; const uint32_t* texels;   // scenes with texture materials only
+  const uint32_t* node_skip;   // links of the stackless walk (trace_lanes)
   int n_spheres, n_lights, has_oct, n_wnodes;
   uint8_t* rgb; int32_t* ids; float* ts; unsigned long long* counters_all; int tally;
   // Tiles of the launch and how they are dealt to the chip's dies (see tile_of): tiles per row / column, strips of
@@ -1016,6 +1084,14 @@ __global__ __launch_bounds__(RT_WBLOCK, (BOUNCE && !QPRIMARY) ? RT_WAVES_PER_SIM
   constexpr bool CLASSES = (!BOUNCE || QPRIMARY) && !COUNT && !RT_PATHS_ON;
 #endif
   constexpr bool queued = wavefront && !QPRIMARY;   // this launch renders a queue of bounce rays, one per lane
+  // Measurement build (tools/build_variant.sh lanes -DRT_LANE_WALK): the rays of a queue walked lane by lane (trace_lanes)
+  // instead of as a wave.  Same bytes; slower: the generations of the glass bunny at 4K take 1.8-2.0 ms each against
+  // 1.2-1.4 ms (frame 6.9 against 5.1 ms; 512x512 2.3 against 2.0 ms) - sorted, the rays of a wave still share most of their walk.
+#ifdef RT_LANE_WALK
+  constexpr bool LANES = queued && !COUNT && !RT_PATHS_ON;
+#else
+  constexpr bool LANES = false;
+#endif
   if (!queued) {
     const Pixel px0 = pixel_of(TID());
     phase = px0.valid ? PH_CLOSEST : PH_DONE;
@@ -1116,7 +1192,8 @@ __global__ __launch_bounds__(RT_WBLOCK, (BOUNCE && !QPRIMARY) ? RT_WAVES_PER_SIM
       const float stop_t = (phase == PH_SHADOW && !COUNT) ? tr_stop : -1.f;
       park<BOUNCE, TEX, QPRIMARY>(sh, MY_PARK());
       asm volatile("" ::: "memory");
-      if (CLASSES) {
+      if (LANES) trace_lanes(nodes, LATE(node_skip), tri_leaf, spheres, n_spheres, has_oct != 0, want, tr_e, tr_d, stop_t, h);
+      else if (CLASSES) {
         float* const bary = parked + (SW + 4) * RT_WBLOCK + (RT_WBLOCK == 64 ? 0 : (TID() & ~63));   // the wave's columns of the two barycentric words
         traced = in_mask(trace_class(nodes, n_wnodes, tri_leaf, spheres, n_spheres, has_oct != 0, want, tr_e, tr_d, stop_t, h, st, bary));
         asm volatile("" ::: "memory");
@@ -1396,7 +1473,7 @@ void rt_launch_wave_kernel(const RtDeviceView& V, const RowMap& rows, bool bounc
   A.cam = V.cam; A.rows = rows; A.tri_geom = V.tri_geom; A.tri_shade = V.tri_shade;
   A.spheres = V.spheres; A.lights = V.lights; A.materials = V.materials; A.mat_index = V.mat_index;
   A.mesh_mat_first = V.mesh_mat_first; A.mesh_mat_count = V.mesh_mat_count;
-  A.tri_uv = V.tri_uv; A.textures = V.textures; A.texels = V.texels;
+  A.tri_uv = V.tri_uv; A.textures = V.textures; A.texels = V.texels; A.node_skip = V.node_skip;
   A.n_spheres = V.n_spheres; A.n_lights = V.n_lights; A.has_oct = V.has_oct; A.n_wnodes = V.n_wnodes;
   A.rgb = rgb; A.ids = ids; A.ts = ts; A.counters_all = counters; A.tally = tally ? 1 : 0; A.wf = wf;
 #define LAUNCH(B, C, Q) hipLaunchKernelGGL((render_wave<B, C, Q>), grid, block, 0, stream, V.wnodes, V.tri_leaf, A)

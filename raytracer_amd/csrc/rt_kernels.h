@@ -17,6 +17,7 @@ struct RtDeviceView {
   const float4* nodes;        // 2 per node
   const float4* wnodes;       // 2 per node, RtWaveNode layout, RT_NODE_VARIANTS copies of n_wnodes records
   int32_t n_wnodes;           // records per copy (nodes + pad)
+  const uint32_t* node_skip;  // per node: the node a stackless walk goes to after the node's subtree (0xffffffff: the walk is over)
   const int32_t* leaf_refs;
   const float4* tri_geom;     // 3 per triangle, indexed by triangle id
   const float4* tri_leaf;     // 4 per leaf reference (RtTriLeaf), in leaf order (same index space as leaf_refs)
