@@ -270,7 +270,10 @@ def main():
                 cycles = kernel_ms * 1e-3 * 2.4e9 * 1024      # SIMD-cycles of the launch at the 2.4 GHz peak clock
                 if "SQ_INSTS_VALU" in c:
                     roofline["valu_insts_per_launch"] = c["SQ_INSTS_VALU"]
-                    roofline["valu_issue_busy"] = c["SQ_INSTS_VALU"] * 4 / cycles      # a wave64 vector instruction holds its SIMD's issue for ~4 cycles
+                    # priced at 4 cycles per wave64 vector instruction: an upper bound (measured in isolation a two-operand one takes
+                    # about 2.7 cycles of its SIMD, a packed or three-source one 4.3-4.8), so the figure can exceed 1
+                    roofline["valu_issue_busy"] = c["SQ_INSTS_VALU"] * 4 / cycles
+                    roofline["valu_issue_busy_is"] = "SQ_INSTS_VALU x 4 cycles / (SIMDs x kernel time x 2.4 GHz): an upper bound, simple instructions issue faster"
                 if "SQ_INSTS_SALU" in c:
                     roofline["salu_smem_insts_per_launch"] = c["SQ_INSTS_SALU"] + c.get("SQ_INSTS_SMEM", 0)
                     roofline["scalar_issue_busy"] = roofline["salu_smem_insts_per_launch"] * 4 / cycles   # one scalar issue per SIMD every 4 cycles
