@@ -357,7 +357,11 @@ int render_wavefront(const SceneArrays& S, RenderCtx& ctx, const RowMap& rows, b
                           (uint32_t*)(base + L.sums), order, stream);
       q.order = order;
     }
+#ifdef RT_WAVE_TIMES
+    rt_launch_wave_kernel(S.view, rows, true, count, nullptr, nullptr, d_t, counters, tally, q, stream);   // (diagnostic build: the waves log their lives there)
+#else
     rt_launch_wave_kernel(S.view, rows, true, count, nullptr, nullptr, nullptr, counters, tally, q, stream);
+#endif
     HIP_TRY(hipGetLastError());
     cur ^= 1u;
   }

@@ -100,13 +100,19 @@ __device__ __forceinline__ uint64_t walk_asm(const float4* nodes, uint32_t varia
   const uint64_t a_nodes = (uint64_t)(uintptr_t)nodes, a_tri = (uint64_t)(uintptr_t)tri_leaf;
   const float cmax = rt_max3(fabsf(fc.x), fabsf(fc.y), fabsf(fc.z));
   float a_det = 0.f, a_nb = 0.f, a_ng = 0.f, a_nt = 0.f;
+#ifdef RT_WALK_PRIO
+  uint32_t a_work = 0u;   // measurement builds: leaves entered by this walk (see RT_PRIO_STEP in rt_trace_asm.inc)
+#define RT_PRIO_OPERAND , "+{s23}"(a_work)
+#else
+#define RT_PRIO_OPERAND
+#endif
   // (one copy of the block per kind of node test inside the one statement: sign-uniform rays (0), or the rays' common
   //  zero pattern (1..6), chosen by s18)
   for (;;) {
     asm volatile(RT_TRACE_ASM
         : "+{s[68:69]}"(a_blk), "+{s70}"(a_rem), "+{s71}"(a_first), "+{s[72:73]}"(a_tmask), "+{s[74:75]}"(a_mine), "+{s[76:77]}"(a_live),
           "+{s78}"(a_idx), "+{s79}"(a_rfirst), "+{s80}"(a_rmeta), "+{s[94:95]}"(a_acc), "+{s[96:97]}"(a_und), "+{s[28:29]}"(a_pass),
-          "+{s20}"(a_tcur), "+{s22}"(a_tend), "+{s[24:25]}"(a_chg), "+{s30}"(a_res), "+{s31}"(a_prim), "+{m0}"(a_sp),
+          "+{s20}"(a_tcur), "+{s22}"(a_tend), "+{s[24:25]}"(a_chg), "+{s30}"(a_res), "+{s31}"(a_prim), "+{m0}"(a_sp) RT_PRIO_OPERAND,
           "+{v60}"(st.first), "+{v61}"(st.cur), "+{v62}"(st.mask_lo), "+{v63}"(st.mask_hi),
           "={v32}"(a_det), "={v33}"(a_nb), "={v35}"(a_ng), "={v36}"(a_nt)
         : "{s[82:83]}"(a_nodes), "{s[92:93]}"(a_tri), "{s18}"(zpat), "{v[40:41]}"(e_xy), "{v42}"(e.z), "{v[44:45]}"(c_zx), "{v[46:47]}"(c_yz),
@@ -1410,6 +1416,23 @@ __global__ __launch_bounds__(RT_WBLOCK, (BOUNCE && !QPRIMARY) ? RT_WAVES_PER_SIM
   }
 #ifdef RT_WAVE_TIMES
   float* const ts = LATE(ts);
+  // (the waves of the queue launches log behind the tiles' records: a counter word, then four words per wave in the order they ended)
+  uint32_t wt_sum = 0u, wt_max = 0u;
+  if (COUNT && ts && queued) {
+    wt_sum = tl.node + tl.tri; wt_max = wt_sum;
+    for (int off = 32; off > 0; off >>= 1) { wt_sum += __shfl_xor(wt_sum, off, 64); const uint32_t o2 = __shfl_xor(wt_max, off, 64); wt_max = o2 > wt_max ? o2 : wt_max; }
+  }
+  if (ts && queued && LANE() == 0) {
+    const unsigned long long wt_end = __builtin_amdgcn_s_memrealtime();
+    uint32_t* const log = (uint32_t*)ts + 4 * (size_t)(((LATE(cam).width + 7) / 8) * ((LATE(cam).height + 7) / 8));
+    const uint32_t at = atomicAdd(log, 1u);
+    if (4ull * (at + 2u) + 4ull * (((LATE(cam).width + 7) / 8) * ((LATE(cam).height + 7) / 8)) <= (unsigned long long)LATE(cam).width * LATE(cam).height) {
+      uint32_t* o = log + 4 + 4 * (size_t)at;
+      o[0] = (uint32_t)wt_start; o[1] = (uint32_t)wt_end; o[2] = (uint32_t)sh.depth; o[3] = blockIdx.x;
+      if (COUNT) { o[2] |= wt_sum << 2; o[3] = wt_max; }   // (with the counting variant: the wave's node + triangle tests, and those of its busiest lane)
+    }
+  }
+  if (ts && !queued && blockIdx.x == 0 && TID() == 0) ((uint32_t*)ts)[4 * (size_t)(((LATE(cam).width + 7) / 8) * ((LATE(cam).height + 7) / 8))] = 0u;
   if (ts && !queued && LANE() == 0) {
     const unsigned long long wt_end = __builtin_amdgcn_s_memrealtime();
     const uint32_t hw = __builtin_amdgcn_s_getreg((31 << 11) | (0 << 6) | 4), xcc = __builtin_amdgcn_s_getreg((31 << 11) | (0 << 6) | 20);

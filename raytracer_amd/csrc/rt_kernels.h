@@ -100,7 +100,7 @@ struct RtQState {     // device-resident bookkeeping of a frame rendered from qu
 static_assert(sizeof(RtQState) == 64, "queue state");
 #define RT_TERM_SLOTS_MAX 128u   // nodes of a pixel's ray tree beyond which bounce rays stay on the lanes' stacks
 #define RT_QUEUE_SORT_MIN 4096u  // shorter queues are rendered in the order they were filled (`order` is not used)
-#define RT_QUEUE_SMALL 131072u   // shorter queues are rendered with 16 rays per wave instead of 64
+#define RT_QUEUE_SMALL 200000u   // shorter queues are rendered with 16 rays per wave instead of 64
 struct RtQueues {
   const RtQRay* in; RtQRay* out;          // in == nullptr: the pass that casts the primary rays
   const uint32_t* order;                  // ray i of the launch is in[order[i]] (nullptr: in[i])

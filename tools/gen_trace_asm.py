@@ -356,6 +356,7 @@ def leaf():
          "s_lshl_b32 %s, %s, 6" % (TEND, TEND),
          "s_add_u32 %s, %s, %s" % (TEND, TEND, TCUR),
          "s_mov_b64 %s, 0" % CHG,
+         "@PRIO",
          "LT_leaf_load_%=:",
          "s_waitcnt lgkmcnt(0)",
          "s_load_dwordx16 s[%d:%d], s[%s:%s], %s" % (TA, TA + 15, TRI[0][1:], TRI[1][1:], TCUR)]
@@ -425,8 +426,16 @@ def main():
             L += [line.replace("LT_", "LT%d_" % pattern) if "LT_end_all" not in line else line for line in B]
             print("pattern", pattern, len(B), "lines")
         L += ["LT_end_all_%=:"]
+        # Measurement builds (-DRT_WALK_PRIO=k): a wave counts the leaves it enters (s23, zeroed by the caller) and raises its issue
+        # priority after 2^k, 2^(k+1) and 2^(k+2) of them (a branch over one instruction is written as its offset, not a label).
+        f.write("#ifdef RT_WALK_PRIO\n#define RT_PRIO_STR2(x) #x\n#define RT_PRIO_STR(x) RT_PRIO_STR2(x)\n"
+                "#define RT_PRIO_STEP \"s_add_u32 s23, s23, 1\\n\" \\\n"
+                "  \"s_bitcmp1_b32 s23, \" RT_PRIO_STR(RT_WALK_PRIO) \"\\n\" \"s_cbranch_scc0 1\\n\" \"s_setprio 1\\n\" \\\n"
+                "  \"s_bitcmp1_b32 s23, \" RT_PRIO_STR(RT_WALK_PRIO) \"+1\\n\" \"s_cbranch_scc0 1\\n\" \"s_setprio 2\\n\" \\\n"
+                "  \"s_bitcmp1_b32 s23, \" RT_PRIO_STR(RT_WALK_PRIO) \"+2\\n\" \"s_cbranch_scc0 1\\n\" \"s_setprio 3\\n\"\n"
+                "#else\n#define RT_PRIO_STEP \"\"\n#endif\n")
         f.write("#define RT_TRACE_ASM \\\n")
-        f.write(" \\\n".join('"%s\\n"' % line for line in L))
+        f.write(" \\\n".join(('RT_PRIO_STEP' if line == "@PRIO" else '"%s\\n"' % line) for line in L))
         f.write("\n")
     print("wrote", os.path.normpath(out))
 

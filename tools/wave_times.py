@@ -10,8 +10,9 @@ import raytracer_amd as rt
 scene = sys.argv[1] if len(sys.argv) > 1 else "meshDragon"
 w, h = (int(x) for x in (sys.argv[2] if len(sys.argv) > 2 else "3840x2160").split("x"))
 ds = rt.DeviceScene(rt.Scene("scenes/%s.json" % scene, w, h, 3))
+counting = len(sys.argv) > 3 and sys.argv[3] == "count"   # the counting variant: the queue waves also log their test counts
 for _ in range(2):
-    rgb, ids, ts, st = ds.render_host(flags=rt.RT_RENDER_TIME)
+    rgb, ids, ts, st = ds.render_host(flags=rt.RT_RENDER_TIME | (rt.RT_RENDER_COUNT_TESTS if counting else 0))
 n = ((w + 7) // 8) * ((h + 7) // 8)
 raw = ts.view(np.uint32).reshape(-1)[:4 * n].reshape(n, 4)
 start = raw[:, 0].astype(np.int64); end = raw[:, 1].astype(np.int64)
@@ -49,3 +50,36 @@ ty = (h + 7) // 8
 grid = dur.reshape(ty, tx)
 print("mean life by tile column block (16 blocks):", [int(grid[:, k * tx // 16:(k + 1) * tx // 16].mean()) for k in range(16)])
 print("centre columns %d..%d mean life: %s" % (tx // 2 - 3, tx // 2 + 2, [int(grid[:, c].mean()) for c in range(tx // 2 - 3, tx // 2 + 3)]))
+# ---- the waves of the queue launches of a frame rendered from queues (logged behind the tiles' records) ----
+words = ts.view(np.uint32).reshape(-1)
+if 4 * n + 4 < words.size and st.get("from_queues"):
+    logged = int(words[4 * n])
+    room = (words.size - 4 * n - 4) // 4
+    m = min(logged, room)
+    q = words[4 * n + 4:4 * n + 4 + 4 * m].reshape(m, 4)
+    qs = q[:, 0].astype(np.int64); qe = q[:, 1].astype(np.int64)
+    qe = np.where(qe < qs, qe + (1 << 32), qe)
+    print("queue launches: %d waves logged (%d ended)" % (m, logged))
+    tests_sum = q[:, 2] >> 2
+    q[:, 2] &= 3
+    for gen in np.unique(q[:, 2]):
+        g = q[:, 2] == gen
+        if counting:
+            life_g = (qe[g] - qs[g]) / 100.0
+            top = np.argsort(-life_g)[:12]
+            print(" generation %d, longest waves: life us / node + triangle tests of the wave / of its busiest lane" % gen)
+            print("   " + "  ".join("%.0f/%d/%d" % (life_g[i], tests_sum[g][i], q[g][i, 3]) for i in top))
+            print("   all waves: tests per wave mean %.0f p99 %.0f max %.0f; busiest lane mean %.0f p99 %.0f max %d; correlation of life with the wave's tests %.3f, with the busiest lane's %.3f"
+                  % (tests_sum[g].mean(), np.percentile(tests_sum[g], 99), tests_sum[g].max(), q[g][:, 3].mean(), np.percentile(q[g][:, 3], 99), q[g][:, 3].max(),
+                     np.corrcoef(life_g, tests_sum[g])[0, 1], np.corrcoef(life_g, q[g][:, 3])[0, 1]))
+            continue
+        a, b = qs[g] - t0, qe[g] - t0
+        life = (b - a) / 100.0
+        span = max(b.max() - a.min(), 1) / 1e5
+        print(" generation %d: %d waves, launch %.3f ms (from %.3f ms); life us mean %.0f median %.0f p90 %.0f p99 %.0f max %.0f; busy wave-ms %.1f = %.0f waves on average"
+              % (gen, g.sum(), span, a.min() / 1e5, life.mean(), np.median(life), np.percentile(life, 90), np.percentile(life, 99), life.max(), life.sum() / 1e3, life.sum() / 1e3 / span))
+        edges2 = np.linspace(a.min(), max(b.max(), a.min() + 10), 11)
+        res = [int(np.clip(np.minimum(b, edges2[k + 1]) - np.maximum(a, edges2[k]), 0, None).sum() / (edges2[k + 1] - edges2[k])) for k in range(10)]
+        print("   resident waves by tenth of the launch:", res)
+        longest = np.argsort(-life)[:8]
+        print("   longest: " + "  ".join("chunk %d %.0f us @%.2f" % (q[g][i, 3], life[i], a[i] / 1e5) for i in longest))
