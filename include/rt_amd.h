@@ -108,6 +108,12 @@ int rt_scene_dump_triangles(const rt_scene* s, float* verts, float* normals, int
 /* DCamera fields (camera/camera.cu:45-74): u v w pos (12 floats), left right bottom top, bg rgb. */
 int rt_scene_dump_camera(const rt_scene* s, float* out19);
 
+/* Optional: bring up the HIP runtime on `device` and load the library's kernels there, so that the first rt_scene_upload
+ * and the first render do not pay for it.  Thread-safe; meant to run on a helper thread beside rt_scene_load (the `run`
+ * command does: runtime start-up takes about as long as parsing and building the meshDragon scene).  The reference
+ * initialises CUDA implicitly with its first cudaMalloc (main.cu:20). */
+int rt_device_prepare(int device);
+
 /* Copy the flattened scene into HBM of HIP device `device`.
  * Replaces the *GPUAdapter constructors (main.cu:20-23,32; one flat upload
  * instead of one cudaMalloc per object). */

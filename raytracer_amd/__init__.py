@@ -29,7 +29,7 @@ RT_RENDER_STRIPS = 32
 # Every symbol include/rt_amd.h declares.
 ABI_SYMBOLS = (
     "rt_scene_load", "rt_scene_destroy", "rt_scene_get_info", "rt_scene_dump_tree", "rt_scene_dump_triangles",
-    "rt_scene_dump_camera", "rt_scene_upload", "rt_dscene_destroy", "rt_dscene_fork", "rt_render_rows", "rt_render_rows_static", "rt_render_rows_host",
+    "rt_scene_dump_camera", "rt_device_prepare", "rt_scene_upload", "rt_dscene_destroy", "rt_dscene_fork", "rt_render_rows", "rt_render_rows_static", "rt_render_rows_host",
     "rt_host_alloc", "rt_host_free", "rt_band_count", "rt_render_bands", "rt_dscene_get_info",
     "rt_comm_unique_id", "rt_comm_init_rank", "rt_comm_init_all", "rt_comm_destroy", "rt_comm_group_begin", "rt_comm_group_end",
     "rt_gather_bands", "rt_unpack_bands", "rt_render_frame_gathered",

@@ -198,6 +198,17 @@ extern "C" void rt_dscene_destroy(rt_dscene* d) {
   delete d;
 }
 
+extern "C" int rt_device_prepare(int device) {
+  int n_dev = 0;
+  if (hipGetDeviceCount(&n_dev) != hipSuccess || n_dev < 1) { rt_set_error("no HIP device is visible; the render path has no CPU fallback"); return RT_ERR_DEVICE; }
+  if (device < 0 || device >= n_dev) { rt_set_error("device index out of range"); return RT_ERR_ARG; }
+  DeviceGuard g(device);
+  HIP_TRY(g.err);
+  HIP_TRY(hipFree(nullptr));   // (creates the device's context)
+  HIP_TRY((hipError_t)rt_preload_wave_kernels());
+  return static_scratch_setup(device);
+}
+
 extern "C" int rt_scene_upload(const rt_scene* s, int device, rt_dscene** out) {
   if (!s || !out) { rt_set_error("rt_scene_upload: NULL argument"); return RT_ERR_ARG; }
   *out = nullptr;

@@ -1463,6 +1463,11 @@ __global__ __launch_bounds__(RT_WBLOCK, (BOUNCE && !QPRIMARY) ? RT_WAVES_PER_SIM
 
 }  // namespace
 
+int rt_preload_wave_kernels() {
+  hipFuncAttributes attr;   // asking for a kernel's attributes makes the runtime load the code object it is in
+  return (int)hipFuncGetAttributes(&attr, reinterpret_cast<const void*>(&render_wave<false, false, false, true>));
+}
+
 void rt_launch_wave_kernel(const RtDeviceView& V, const RowMap& rows, bool bounce, bool count, uint8_t* rgb, int32_t* ids,
                            float* ts, unsigned long long* counters, bool tally, const RtQueues& wf, hipStream_t stream) {
   const int tw = rows.small ? RT_WTILE_W / 2 : RT_WTILE_W, th = rows.small ? RT_WTILE_H / 2 : RT_WTILE_H;

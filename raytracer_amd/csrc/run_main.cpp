@@ -16,6 +16,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "../../include/rt_amd.h"
@@ -55,6 +56,10 @@ int main(int ac, char** av) {
   if (gpus < 0 || gpus > 64) { fprintf(stderr, "run: --gpus must be 1..64\n"); return 1; }
   if (gpus > 0 && ids_path) { fprintf(stderr, "run: --dump-ids is a single-GPU option\n"); return 1; }
 
+  // the HIP runtime comes up on a thread of its own while this one parses the scene and builds the octree
+  // (a failure there is reported by rt_scene_upload below, which does the same steps again)
+  std::thread bring_up([&] { for (int r = 0; r < (gpus > 0 ? gpus : 1); r++) (void)rt_device_prepare(gpus > 0 ? r : device); });
+  struct Joiner { std::thread& t; ~Joiner() { if (t.joinable()) t.join(); } } joiner{bring_up};
   rt_scene* sc = nullptr;
   int rc = rt_scene_load(option_value(ac, av, "-s"), res.c_str(), "", W, H, depth, &sc);
   if (rc != RT_OK) {
@@ -65,6 +70,7 @@ int main(int ac, char** av) {
   rt_scene_info info;
   rt_scene_get_info(sc, &info);
   const auto t_up = clk::now();
+  bring_up.join();
   const int n_dev = gpus > 0 ? gpus : 1;
   std::vector<rt_dscene*> ds(n_dev, nullptr);
   std::vector<rt_comm*> comms(n_dev, nullptr);

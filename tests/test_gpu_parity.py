@@ -384,6 +384,15 @@ def test_forked_contexts_share_one_upload_and_render_concurrently():
         assert np.array_equal(rgb, alone) and st["rays"] == st_alone["rays"]
 
 
+def test_device_prepare_is_optional_and_repeatable():
+    L = rt.lib()
+    assert L.rt_device_prepare(0) == 0 and L.rt_device_prepare(0) == 0
+    assert L.rt_device_prepare(-1) == -1 and L.rt_device_prepare(1 << 20) == -1
+    sc = rt.Scene("scenes/sphere.json", 64, 64, 3)
+    rgb = rt.DeviceScene(sc).render_host()[0]
+    assert rgb.shape == (64, 64, 3) and rgb.any()
+
+
 def test_entry_points_leave_the_current_device_alone():
     import torch
     before = torch.cuda.current_device()

@@ -97,6 +97,15 @@ def test_error_codes(tmp_path):
     assert e.value.status == -2
 
 
+def test_device_prepare_without_a_device_says_so():
+    # (no CPU fallback: on a machine without a HIP device the optional bring-up call reports RT_ERR_DEVICE like the upload does)
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is visible")
+    assert rt.lib().rt_device_prepare(0) == -5
+    assert b"no HIP device" in rt.lib().rt_last_error()
+
+
 def test_png_writer_roundtrip(tmp_path):
     rng = np.random.default_rng(7)
     for (h, w) in ((1, 1), (37, 53), (300, 257)):
