@@ -233,6 +233,7 @@ extern "C" int rt_scene_upload(const rt_scene* s, int device, rt_dscene** out) {
   UP(mesh_mat_first, s->mesh_mat_first) UP(mesh_mat_count, s->mesh_mat_count)
   if (!s->textures.empty()) { UP(tri_uv, s->tri_uv) UP(textures, s->textures) UP(texels, s->texels) }   // only scenes with texture materials
 #undef UP
+  V.cull_offset = s->cull_offset;
   V.n_spheres = (int32_t)s->spheres.size(); V.n_lights = (int32_t)s->lights.size(); V.has_oct = s->nodes.empty() ? 0 : 1; V.n_wnodes = (int32_t)s->nodes.size();
   if ((rc = arena_reserve(d->ctx.arena, RT_COUNTER_BYTES, "rt_scene_upload")) != RT_OK) { d->ctx.release(); return rc; }
   if ((rc = static_scratch_setup(device)) != RT_OK) { d->ctx.release(); return rc; }

@@ -21,6 +21,7 @@
 #include <zlib.h>
 
 #include "rt_internal.h"
+#include "rt_math.h"
 
 // ------------------------------------------------------------------ errors
 static thread_local std::string g_last_error;
@@ -772,8 +773,14 @@ void load_scene_into(rt_scene& sc, const std::string& scene_path, const std::str
     TreeBuilder tb(sc); tb.build();
     // Leaf-ordered copy of the intersection records: a leaf's triangles are one contiguous run, so the
     // traversal streams them without the index indirection.
-    // One extra record at the end of both arrays, so that the traversal may always prefetch "the next one".
-    sc.tri_leaf.assign(sc.leaf_refs.size() + 1, RtTriLeaf{});
+    // RT_LEAF_PAD extra records at the end, so that the traversal may always request "the next one" (the walk's
+    // end-of-leaf marker stands for record 63 of the leaf).  Behind them, in the same array, one RtCullRec per
+    // record (and as many pads: lane k of a wave reads record k of the leaf it enters, whatever the leaf's length).
+    const size_t n_rec = sc.leaf_refs.size() + RT_LEAF_PAD;
+    sc.tri_leaf.assign(n_rec + (n_rec * sizeof(RtCullRec) + sizeof(RtTriLeaf) - 1) / sizeof(RtTriLeaf), RtTriLeaf{});
+    sc.cull_offset = (uint32_t)(n_rec * sizeof(RtTriLeaf));
+    RtCullRec* const cull = reinterpret_cast<RtCullRec*>(sc.tri_leaf.data() + n_rec);
+    for (size_t r = sc.leaf_refs.size(); r < n_rec; r++) cull[r] = RtCullRec{0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, __builtin_inff()};
     for (size_t r = 0; r < sc.leaf_refs.size(); r++) {
       const RtTriGeom& g = sc.tri_geom[sc.leaf_refs[r]];
       RtTriLeaf& t = sc.tri_leaf[r];
@@ -784,6 +791,7 @@ void load_scene_into(rt_scene& sc, const std::string& scene_path, const std::str
       t.nx = g.e1[1] * g.e2[2] - g.e1[2] * g.e2[1];
       t.ny = -g.e1[0] * g.e2[2] + g.e1[2] * g.e2[0];
       t.nz = g.e1[0] * g.e2[1] - g.e1[1] * g.e2[0];
+      cull[r] = rt_cull_record(g.v0, g.e1, g.e2);
     }
     // The walk visits children in the fixed order 0..7 whatever the ray, so "what comes after this subtree" is a property of
     // the node: its next sibling that is not an empty leaf, else what comes after its parent.  With that link per node a

@@ -14,6 +14,7 @@
 #define RT_EPS 0.001f
 #define RT_NEAR 0.1f
 #define RT_LEAF_CAP 50
+#define RT_LEAF_PAD 64   // records behind the last leaf's that a walk may still request
 #define RT_RAY_STACK 10
 #define RT_OCT_STACK 20
 #define RT_MAX_LEVELS 3
@@ -101,7 +102,8 @@ struct rt_scene {
   std::vector<uint32_t> node_skip;                // per node: where a walk in the fixed child order goes when it is done with the node's subtree (see rt_host.cpp)
   std::vector<int32_t> leaf_refs;
   std::vector<RtTriGeom> tri_geom;
-  std::vector<RtTriLeaf> tri_leaf;                // intersection records repeated in leaf order (index space of leaf_refs), plus one pad record
+  std::vector<RtTriLeaf> tri_leaf;                // intersection records repeated in leaf order (index space of leaf_refs), RT_LEAF_PAD pad records, then the RtCullRec array
+  uint32_t cull_offset = 0;                       // byte offset of that array from the start of tri_leaf (0: no mesh)
   std::vector<RtTriShade> tri_shade;
   std::vector<float> tri_verts, tri_normals;      // n*9 each, as the reference uploads them
   std::vector<float> tri_uv;                      // n*6: texture coordinates of the three corners (parsing.cu:54-63,102-108; zeros without `vt` lines)

@@ -69,6 +69,26 @@ __device__ __forceinline__ float wave_min(float v) {
   return __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, fminf(fminf(r0, r1), fminf(r2, r3)))));
 }
 
+// Maximum / sum over the 64 lanes the same way.
+__device__ __forceinline__ float wave_max(float v) {
+  v = fmaxf(v, __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xB1, 0xf, 0xf, true)));
+  v = fmaxf(v, __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x4E, 0xf, 0xf, true)));
+  v = fmaxf(v, __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x141, 0xf, 0xf, true)));
+  v = fmaxf(v, __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x140, 0xf, 0xf, true)));
+  const float r0 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 0)), r1 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 16)),
+              r2 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 32)), r3 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 48));
+  return __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, fmaxf(fmaxf(r0, r1), fmaxf(r2, r3)))));
+}
+__device__ __forceinline__ float wave_sum(float v) {
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xB1, 0xf, 0xf, true));
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x4E, 0xf, 0xf, true));
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x141, 0xf, 0xf, true));
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x140, 0xf, 0xf, true));
+  const float r0 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 0)), r1 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 16)),
+              r2 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 32)), r3 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 48));
+  return __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, (r0 + r1) + (r2 + r3))));
+}
+
 // Index of the lane within its wave, derived on the spot (the compiler may not keep the result of a volatile statement
 // for a later use, which is the point: see render_wave).
 __device__ __forceinline__ int fresh_lane_id() {
@@ -81,6 +101,38 @@ __device__ __forceinline__ int fresh_lane_id() {
 // would keep a 64-bit per-lane value alive wherever it is used.)
 __device__ __forceinline__ bool in_mask(uint64_t mask) { return __builtin_amdgcn_inverse_ballot_w64(mask); }
 
+// The bundle of the rays in `cls` (rt_math.h: RtBundle, rt_cull_test) for the walk's triangle skipping, left in lanes
+// 32 .. 41 of the stack's first register (the stack itself never gets beyond lane 19).  The point the lines pass close
+// to is taken from the first ray: its origin, or for a shadow ray the point at the light's distance (the rays towards a
+// point light all pass through the light; primary rays share the eye; parallel rays only need some point).  Returns
+// false when the bundle is too wide to rule anything out (rays that have little in common): the walk then tests every
+// triangle as it comes.  All 64 lanes must be active.
+#ifndef RT_CULL_R0_MAX
+#define RT_CULL_R0_MAX 1.0f
+#endif
+#ifndef RT_CULL_KSP_MAX
+#define RT_CULL_KSP_MAX 0.25f
+#endif
+__device__ __forceinline__ bool wave_bundle(uint64_t cls, const RtVec3& e, const RtVec3& d, float stop_t, WaveStack& st) {
+  const bool in = in_mask(cls);
+  const float h = stop_t >= 0.f ? fminf(stop_t, RT_INF) : 0.f;
+  const int first = __builtin_ctzll(cls);
+  auto from_first = [&](float v) { return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), first)); };
+  const RtVec3 o = {from_first(fmaf(h, d.x, e.x)), from_first(fmaf(h, d.y, e.y)), from_first(fmaf(h, d.z, e.z))};
+  const RtVec3 sum = {wave_sum(in ? d.x : 0.f), wave_sum(in ? d.y : 0.f), wave_sum(in ? d.z : 0.f)};
+  const float len = rt_len(sum);
+  if (!(len > 0.5f)) return false;   // (directions that cancel: certainly not a bundle)
+  const RtVec3 a = {sum.x / len, sum.y / len, sum.z / len};
+  float r0, bw, k;
+  rt_bundle_lane(o, a, e, d, r0, bw, k);
+  r0 = wave_max(in ? r0 : 0.f); bw = wave_max(in ? bw : 0.f); k = wave_max(in ? k : 0.f);
+  if (!(r0 <= RT_CULL_R0_MAX && k <= RT_CULL_KSP_MAX && bw < 1e6f)) return false;   // (also false for NaN)
+  const RtBundle B = rt_bundle_finish(o, a, r0, bw, k);
+  const float p[10] = {B.ox, B.oy, B.oz, B.ax, B.ay, B.az, B.r0, B.ksp, B.k1, B.bw};
+for (int i = 0; i < 10; i++) st.first = in_mask(1ull << (32 + i)) ? __float_as_uint(p[i]) : st.first;
+  return true;
+}
+
 // The walk of a set of rays (`live`) that agree on their direction signs (`variant`: the copy of the node array whose plane
 // pairs are in (near, far) order for them; zpat 0) or share the pattern `zpat` of zero direction components (variant 0),
 // as one block of assembly - see the call in trace_wave for what the block does and which registers it owns.
@@ -89,9 +141,12 @@ __device__ __forceinline__ bool in_mask(uint64_t mask) { return __builtin_amdgcn
 // bary_lds != nullptr: the barycentrics of an accepted triangle go to LDS (word 0 and word RT_WBLOCK of the lane's column
 // there) instead of into `hit` - they change a few times per walk and are read once per closest hit, and as part of `hit`
 // they would be carried through the whole walk in two registers.
+// cull != 0: byte offset of the RtCullRec array behind the triangle records, and lanes 32 .. 41 of st.first hold the
+// bundle of the rays in `live` (wave_bundle): on entering a leaf the walk leaves out the triangles that no ray of the
+// bundle can be accepted by.  cull == 0: every triangle of every leaf entered is tested.
 __device__ __forceinline__ uint64_t walk_asm(const float4* nodes, uint32_t variant, uint32_t zpat, const float4* tri_leaf, uint32_t top_first, uint32_t rem,
                                              uint64_t live, const RtVec3& e, const RtVec3& d, const RtVec3& inv, const RtVec3& fc, float neg_eb,
-                                             float stop_t, Hit& hit, WaveStack& st, float* bary_lds) {
+                                             float stop_t, Hit& hit, WaveStack& st, float* bary_lds, uint32_t cull) {
   const RtVec3 c2 = {-d.x, -d.y, -d.z};                   // third column of the triangle solve (triangle.cu:118-120)
   const v2f e_xy = {e.x, e.y}, c_zx = {c2.z, c2.x}, c_yz = {c2.y, c2.z}, c_yx = {c2.y, c2.x};
   uint64_t a_blk = (uint64_t)(uintptr_t)(nodes + 2 * (size_t)top_first);
@@ -115,7 +170,7 @@ __device__ __forceinline__ uint64_t walk_asm(const float4* nodes, uint32_t varia
           "+{s20}"(a_tcur), "+{s22}"(a_tend), "+{s[24:25]}"(a_chg), "+{s30}"(a_res), "+{s31}"(a_prim), "+{m0}"(a_sp) RT_PRIO_OPERAND,
           "+{v60}"(st.first), "+{v61}"(st.cur), "+{v62}"(st.mask_lo), "+{v63}"(st.mask_hi),
           "={v32}"(a_det), "={v33}"(a_nb), "={v35}"(a_ng), "={v36}"(a_nt)
-        : "{s[82:83]}"(a_nodes), "{s[92:93]}"(a_tri), "{s18}"(zpat), "{v[40:41]}"(e_xy), "{v42}"(e.z), "{v[44:45]}"(c_zx), "{v[46:47]}"(c_yz),
+        : "{s[82:83]}"(a_nodes), "{s[92:93]}"(a_tri), "{s18}"(zpat), "{s19}"(cull), "{v[40:41]}"(e_xy), "{v42}"(e.z), "{v[44:45]}"(c_zx), "{v[46:47]}"(c_yz),
           "{v[48:49]}"(c_yx), "{v50}"(inv.x), "{v51}"(inv.y), "{v52}"(inv.z), "{v53}"(fc.x), "{v54}"(fc.y), "{v55}"(fc.z), "{v56}"(cmax),
           "{v57}"(neg_eb), "{v58}"(hit.t), "{v59}"(stop_t)
         : "s36", "s37", "s38", "s39", "s40", "s41", "s42", "s43", "s44", "s45", "s46", "s47", "s48", "s49", "s50", "s51", "s52", "s53", "s54", "s55",
@@ -294,7 +349,7 @@ __device__ __forceinline__ void trace_wave(const float4* __restrict__ nodes, int
     // closest hit so far, shadow-ray length), v[60:63] the wave's stack, v32 v33 v35 v36 determinant and numerators
     // of a candidate, v34 v37:v39 v64:v79 scratch.
     if ((presorted || zpat != 0u) && FUSED && (rem & 0xffu) != 0u) {
-      live = walk_asm(nodes, variant, zpat, tri_leaf, top_first, rem, live, e, d, inv, fc, neg_eb, stop_t, hit, st, nullptr);
+      live = walk_asm(nodes, variant, zpat, tri_leaf, top_first, rem, live, e, d, inv, fc, neg_eb, stop_t, hit, st, nullptr, 0u);
       if (!live) return;
     } else {
 #endif
@@ -756,7 +811,8 @@ __device__ __forceinline__ void trace_wave(const float4* __restrict__ nodes, int
 // test of the lane goes to the exact test, which does not use the inverse.
 __device__ __forceinline__ uint64_t trace_class(const float4* __restrict__ nodes, int n_wnodes, const float4* __restrict__ tri_leaf,
                                                 const RtSphere* __restrict__ spheres, int n_spheres, bool has_oct, bool want,
-                                                const RtVec3& e, const RtVec3& d, float stop_t, Hit& hit, WaveStack& st, float* bary_lds) {
+                                                const RtVec3& e, const RtVec3& d, float stop_t, Hit& hit, WaveStack& st, float* bary_lds,
+                                                uint32_t cull_offset) {
   const uint64_t pending = __builtin_amdgcn_ballot_w64(want);
   if (!pending) return 0ull;
   uint64_t cls = pending, after = pending;
@@ -785,7 +841,8 @@ __device__ __forceinline__ uint64_t trace_class(const float4* __restrict__ nodes
         const f4 ra = *(cnode_ptr)(uintptr_t)vnodes, rb = *((cnode_ptr)(uintptr_t)vnodes + 1);
         neg_eb = -rt_slab_margin_bound_fused(ra.x, ra.y, ra.z, ra.w, rb.x, rb.y, e, inv, fu, hit.t);
       }
-      after = walk_asm(vnodes, variant, zpat, tri_leaf, top_first, rem, cls, e, d, inv, fu.c, neg_eb, stop_t, hit, st, bary_lds);
+      const uint32_t cull = (cull_offset != 0u && wave_bundle(cls, e, d, stop_t, st)) ? cull_offset : 0u;
+      after = walk_asm(vnodes, variant, zpat, tri_leaf, top_first, rem, cls, e, d, inv, fu.c, neg_eb, stop_t, hit, st, bary_lds, cull);
     }
   }
   if (n_spheres > 0 && after) {
@@ -952,6 +1009,7 @@ struct RtWaveArgs {
   const float* tri_uv; const RtTexture* textures; const uint32_t* texels;   // scenes with texture materials only
   const uint32_t* node_skip;   // links of the stackless walk (trace_lanes)
   int n_spheres, n_lights, has_oct, n_wnodes;
+  uint32_t cull_offset, pad_;   // bytes from tri_leaf to its RtCullRec array; 0: the walk tests every triangle (RT_AMD_NO_CULL, measurements)
   uint8_t* rgb; int32_t* ids; float* ts; unsigned long long* counters_all; int tally;
   // Tiles of the launch and how they are dealt to the chip's dies (see tile_of): tiles per row / column, strips of
   // RT_STRIP_W tile columns per die (0: a plain two-dimensional grid, one workgroup per tile)
@@ -1201,7 +1259,7 @@ __global__ __launch_bounds__(RT_WBLOCK, (BOUNCE && !QPRIMARY) ? RT_WAVES_PER_SIM
       if (LANES) trace_lanes(nodes, LATE(node_skip), tri_leaf, spheres, n_spheres, has_oct != 0, want, tr_e, tr_d, stop_t, h);
       else if (CLASSES) {
         float* const bary = parked + (SW + 4) * RT_WBLOCK + (RT_WBLOCK == 64 ? 0 : (TID() & ~63));   // the wave's columns of the two barycentric words
-        traced = in_mask(trace_class(nodes, n_wnodes, tri_leaf, spheres, n_spheres, has_oct != 0, want, tr_e, tr_d, stop_t, h, st, bary));
+        traced = in_mask(trace_class(nodes, n_wnodes, tri_leaf, spheres, n_spheres, has_oct != 0, want, tr_e, tr_d, stop_t, h, st, bary, LATE(cull_offset)));
         asm volatile("" ::: "memory");
         h.bet = bary[LANE()]; h.gam = bary[RT_WBLOCK + LANE()];   // (only meaningful, and only used, when a triangle was hit)
       }
@@ -1503,6 +1561,8 @@ void rt_launch_wave_kernel(const RtDeviceView& V, const RowMap& rows, bool bounc
   A.mesh_mat_first = V.mesh_mat_first; A.mesh_mat_count = V.mesh_mat_count;
   A.tri_uv = V.tri_uv; A.textures = V.textures; A.texels = V.texels; A.node_skip = V.node_skip;
   A.n_spheres = V.n_spheres; A.n_lights = V.n_lights; A.has_oct = V.has_oct; A.n_wnodes = V.n_wnodes;
+  static const bool no_cull = getenv("RT_AMD_NO_CULL") != nullptr;
+  A.cull_offset = no_cull ? 0u : V.cull_offset; A.pad_ = 0u;
   A.rgb = rgb; A.ids = ids; A.ts = ts; A.counters_all = counters; A.tally = tally ? 1 : 0; A.wf = wf;
 #define LAUNCH(B, C, Q) hipLaunchKernelGGL((render_wave<B, C, Q>), grid, block, 0, stream, V.wnodes, V.tri_leaf, A)
   if (V.textures) {   // (never from queues: rt_device.hip keeps scenes with texture materials on the stacks)

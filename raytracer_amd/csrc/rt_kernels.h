@@ -21,6 +21,7 @@ struct RtDeviceView {
   const int32_t* leaf_refs;
   const float4* tri_geom;     // 3 per triangle, indexed by triangle id
   const float4* tri_leaf;     // 4 per leaf reference (RtTriLeaf), in leaf order (same index space as leaf_refs)
+  uint32_t cull_offset;       // bytes from tri_leaf to the RtCullRec of leaf reference 0 (same array)
   const float4* tri_shade;    // 4 per triangle
   const RtSphere* spheres;
   const RtLight* lights;

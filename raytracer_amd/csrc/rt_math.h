@@ -527,4 +527,106 @@ RT_HD void rt_node_slab_class2(const RtVec3& lo, const RtVec3& hi, const RtVec3&
   accepted = c > 0; undecided = c == 0;
 }
 
+// ------------------------------------------------------------------------------------------------
+// Leaf triangles a whole wave can skip.
+//
+// A leaf of the octree holds up to 50 triangles that merely touch its cube, and the reference tests a ray that enters
+// the cube against all of them (octtree.cu:264-274); nine tests in ten are on triangles nowhere near the ray.  A test
+// that the reference is certain to reject changes nothing (triangle.cu:137 only acts on acceptance), so the wave kernel
+// leaves such tests out when it can prove the rejection for all of its rays at once: on entering a leaf, lane k takes
+// triangle k and asks whether any ray of the wave's BUNDLE can come near it.
+//
+// The bundle (RtBundle) bounds the wave's ray lines: every point X of every line lies within r0 + ksp * s of the axis
+// (o, a), s being the distance of X from the point of its line nearest o (o is a point all the lines pass close to - the
+// eye, a point light - or just a point of one of them; a is their mean direction; r0 the largest distance of a line
+// from o, ksp the largest |d - a|).  A line that enters the ball (c, R') therefore does so at s <= |c - o| + R', i.e.
+// within r0 + ksp (|c - o| + R') of the axis, and cannot if the centre is further from the axis than that plus R'.
+//
+// What R' has to be for "the line misses the ball" to imply "triangle.cu:107-152 rejects", in float arithmetic:
+// with b = eye - v0, n = e1 x e2 and det = -d.n, the reference accepts only if its rounded numerators satisfy
+// 0 <= nb / det, 0 <= ng / det and 1 - nb / det - ng / det >= 0.  The rounded numerators differ from the exact ones by at
+// most E_b = c u |b||e2|, E_g = c u |b||e1|, E_d = c u |e1||e2| (u = 2^-24; c < 10 from the operation count of
+// rt_cofactor_solve).  If |det| >= tau > 2 E_d the computed det has the exact one's sign, and acceptance implies for the
+// exact solution beta >= -E_b / tau, gamma >= -E_g / tau, beta + gamma <= 1 + 2u + (E_b + E_g + 2 E_d) / tau: the
+// point where the line meets the triangle's plane lies in the triangle scaled about its centroid by 1 + 3 mu,
+// mu = c u (|b| (|e1| + |e2|) + 2 |e1||e2|) / tau, hence in the ball of radius R (1 + 3 mu) about the centroid (R: the
+// largest distance of a corner).  With tau = cosn sinphi |e1||e2| (cosn: a lower bound of |d.n| / |n| over the wave's
+// rays, sinphi = |n| / (|e1||e2|)) that is R' = R + Q (|b| + 2R) / cosn with Q = 3 R c u (1/|e1| + 1/|e2|) / sinphi
+// stored per triangle (c = 64 there, for slack; the last term uses 2|e1||e2| / (|e1| + |e2|) <= 2R).
+// Rays nearly in the triangle's plane (small |det|) are where the reference's quotients are noise and may accept
+// anything: the test therefore never skips a triangle unless cosn > 2^-10, and slivers (sinphi < 1/64) and degenerate
+// triangles carry Q = +inf, which never passes.
+struct RtCullRec { float cx, cy, cz, R, nx, ny, nz, Q; };   // 32 B per leaf reference, in leaf order behind the triangle records
+struct RtBundle { float ox, oy, oz, ax, ay, az, r0, ksp, k1, bw; };   // k1 = 1 + ksp; bw >= |eye - o| for every ray
+#define RT_CULL_GUARD 0x1p-10f
+#define RT_CULL_P2_SLACK (-0x1p-19f)
+
+#if !defined(__HIPCC__) || !defined(__HIP_DEVICE_COMPILE__)
+// Host: the record of a triangle (double arithmetic, rounded away from the safe side with room to spare).
+inline RtCullRec rt_cull_record(const float* v0, const float* e1, const float* e2) {
+  RtCullRec r;
+  double c[3], n[3], R = 0, l1 = 0, l2 = 0, nl = 0;
+  for (int k = 0; k < 3; k++) { c[k] = (double)v0[k] + ((double)e1[k] + (double)e2[k]) / 3.0; l1 += (double)e1[k] * e1[k]; l2 += (double)e2[k] * e2[k]; }
+  n[0] = (double)e1[1] * e2[2] - (double)e1[2] * e2[1]; n[1] = (double)e1[2] * e2[0] - (double)e1[0] * e2[2]; n[2] = (double)e1[0] * e2[1] - (double)e1[1] * e2[0];
+  for (int k = 0; k < 3; k++) nl += n[k] * n[k];
+  l1 = sqrt(l1); l2 = sqrt(l2); nl = sqrt(nl);
+  for (int q = 0; q < 3; q++) {
+    double s = 0;
+    for (int k = 0; k < 3; k++) { const double p = (double)v0[k] + (q == 1 ? (double)e1[k] : q == 2 ? (double)e2[k] : 0.0) - c[k]; s += p * p; }
+    if (sqrt(s) > R) R = sqrt(s);
+  }
+  r.cx = (float)c[0]; r.cy = (float)c[1]; r.cz = (float)c[2];
+  double shift = 0;   // the centre moved by its rounding to float: the radius grows by as much
+  for (int k = 0; k < 3; k++) { const double dk = (double)(k == 0 ? r.cx : k == 1 ? r.cy : r.cz) - c[k]; shift += dk * dk; }
+  r.R = (float)((R + sqrt(shift)) * 1.001 + 1e-6);
+  const float inf = __builtin_inff();
+  r.nx = r.ny = r.nz = 0.f; r.Q = inf;
+  if (nl > 0 && l1 > 0 && l2 > 0 && std::isfinite(nl) && std::isfinite(R)) {
+    const double sinphi = nl / (l1 * l2);
+    r.nx = (float)(n[0] / nl); r.ny = (float)(n[1] / nl); r.nz = (float)(n[2] / nl);
+    if (sinphi >= 1.0 / 64) {
+      const double Q = 3.0 * R * 64.0 * 0x1p-24 * (1.0 / l1 + 1.0 / l2) / sinphi * 1.01;
+      if (std::isfinite(Q)) r.Q = (float)(Q * 1.001);
+    }
+  }
+  return r;
+}
+#endif
+
+// A ray's share of the bundle around axis (o, a): its line's distance from o, its origin's distance from o, |d - a|.
+// (The distance comes from the cross product: a difference of squares would lose it for a far-away o.)
+RT_HD void rt_bundle_lane(const RtVec3& o, const RtVec3& a, const RtVec3& e, const RtVec3& d, float& r0, float& bw, float& k) {
+  const RtVec3 w = {o.x - e.x, o.y - e.y, o.z - e.z};
+  const RtVec3 c = {w.y * d.z - w.z * d.y, w.z * d.x - w.x * d.z, w.x * d.y - w.y * d.x};
+  const RtVec3 q = {d.x - a.x, d.y - a.y, d.z - a.z};
+  r0 = sqrtf(rt_dot(c, c)); bw = sqrtf(rt_dot(w, w)); k = sqrtf(rt_dot(q, q));
+}
+// The bundle from the largest of those over the wave's rays, rounded up with room for the rounding of everything above
+// and of the lane test (directions and axis are unit vectors to within 2^-22).
+RT_HD RtBundle rt_bundle_finish(const RtVec3& o, const RtVec3& a, float r0, float bw, float k) {
+  RtBundle B;
+  B.ox = o.x; B.oy = o.y; B.oz = o.z; B.ax = a.x; B.ay = a.y; B.az = a.z;
+  B.r0 = fmaf(r0, 1.001f, fmaf(bw, 0x1p-18f, 1e-6f));
+  B.ksp = fmaf(k, 1.001f, 0x1p-18f);
+  B.k1 = (1.f + B.ksp) * 1.000001f;
+  B.bw = fmaf(bw, 1.001f, 1e-4f);
+  return B;
+}
+
+// Lane k's question about triangle k, as the assembly asks it (fused multiply-adds are fine here: this is not the
+// reference's arithmetic, only a bound).  true: no ray of the bundle can be accepted by this triangle.
+RT_HD bool rt_cull_test(const RtCullRec& t, const RtBundle& B) {
+  const float vx = t.cx - B.ox, vy = t.cy - B.oy, vz = t.cz - B.oz;
+  const float vv = fmaf(vz, vz, fmaf(vy, vy, vx * vx));
+  const float tc = fmaf(B.az, vz, fmaf(B.ay, vy, B.ax * vx));
+  float p2 = fmaf(-tc, tc, vv);
+  p2 = fmaf(RT_CULL_P2_SLACK, vv, p2);   // what rounding can have added to vv - tc^2
+  const float p = sqrtf(fmaxf(p2, 0.f)), vl = sqrtf(vv);
+  const float cosn = fabsf(fmaf(B.az, t.nz, fmaf(B.ay, t.ny, B.ax * t.nx))) - B.ksp;
+  const float reach = fmaf(B.ksp, vl, fmaf(t.R, B.k1, B.r0));          // r0 + R k1 + ksp |v|
+  const float lhs = (p - reach) * cosn;
+  const float rhs = t.Q * fmaf(4.f, t.R, B.bw + vl) * B.k1;            // margin (1 + ksp) cosn, with |b| <= bw + |v| + R
+  return lhs > rhs && cosn > RT_CULL_GUARD;
+}
+
 #endif

@@ -23,6 +23,13 @@ ACC, UND, NR = "s[94:95]", "s[96:97]", "s[98:99]"
 # below 4 GiB: rt_device.hip checks): TCUR / TNXT take turns as "offset of the record under test" and "offset of the record
 # behind it, which is on its way", TEND is the offset behind the leaf's last record.
 TCUR, TNXT, TEND = "s20", "s21", "s22"
+# Which of a leaf's triangles are still to be tested is a bit mask (SURV; bit 63 is always set while the leaf is open: "record
+# 63", which no leaf has, marks the end, so that "the next one" can be requested without asking whether there is one).
+# The mask starts as the triangles that the wave's bundle of rays can possibly be accepted by (cull(): lane k looks at
+# triangle k of the leaf; rt_cull_test in rt_math.h), or as all of them when the caller passes no bundle (CULL = 0).
+# Outside the block the mask waits in lanes 62 / 63 of the stack register ST_FIRST, whose lanes 32 .. 41 hold the bundle.
+SURV, JT = "s[98:99]", "s22"       # (SURV shares the registers of NR, which only lives within the scan; TEND only carries the leaf's triangle count into the mask; then it is the scratch index JT)
+CULL = "s19"                     # byte offset of the RtCullRec array from the triangle records, 0: test every triangle
 CHG, T64, PASS = "s[24:25]", "s[26:27]", "s[28:29]"
 RES, RPRIM = "s30", "s31"
 
@@ -293,7 +300,10 @@ def triangle(q, other, tag, cur, nxt):
          "v_pk_mul_f32 v[78:79], %s, v[70:71]" % bxy,                                           # b.x m00 , b.y m10
          "v_add_f32 v76, v76, v77",
          "v_mul_f32 v77, %s, v75" % s(q + 6),                                                   # e1.z m20
-         "s_add_u32 %s, %s, 0x40" % (nxt, cur),
+         "s_ff1_i32_b64 %s, %s" % (JT, SURV),
+         "s_bitset0_b64 %s, %s" % (SURV, JT),
+         "s_add_u32 %s, %s, %s" % (JT, JT, RFIRST),
+         "s_lshl_b32 %s, %s, 6" % (nxt, JT),
          "s_load_dwordx16 s[%d:%d], s[%s:%s], %s" % (other, other + 15, TRI[0][1:], TRI[1][1:], nxt),
          "v_add_f32 %s, v76, v77" % det,
          "v_add_f32 v78, v78, v79",
@@ -342,9 +352,66 @@ def triangle(q, other, tag, cur, nxt):
          # candidates: the quotients are formed outside; the walk goes on behind this record
          "s_mov_b32 %s, %s" % (RPRIM, s(q + 3)),
          "s_mov_b32 %s, %s" % (TCUR, nxt),                                                       # where the leaf goes on afterwards
+         "v_writelane_b32 %s, s98, 62" % ST_FIRST,
+         "v_writelane_b32 %s, s99, 63" % ST_FIRST,
          "s_mov_b32 %s, 2" % RES,
          "s_branch LT_out_%=",
          "LT_end%s_%%=:" % tag]
+    return L
+
+
+def cull():
+    """Lane k of the wave (all 64 lanes, whatever the walk's lane sets say) and triangle k of the leaf: rt_cull_test of rt_math.h.
+    Leaves the triangles worth testing in SURV, or goes on to the next child when there is none."""
+    P = ["s%d" % (36 + i) for i in range(10)]      # ox oy oz ax ay az r0 ksp k1 bw (the triangle registers are free here)
+    ox, oy, oz, ax, ay, az, r0, ksp, k1, bw = P
+    L = ["s_waitcnt lgkmcnt(0)",                                      # (a request of the leaf before may still be on its way into those registers)
+         "s_mov_b64 %s, exec" % SURV,
+         "s_mov_b64 exec, -1",
+         "v_mbcnt_lo_u32_b32 v72, -1, 0",
+         "v_mbcnt_hi_u32_b32 v72, -1, v72",
+         "v_add_u32 v72, %s, v72" % RFIRST,
+         "v_lshlrev_b32 v72, 5, v72",
+         "v_add_u32 v72, %s, v72" % CULL,
+         "global_load_dwordx4 v[64:67], v72, s[%s:%s]" % (TRI[0][1:], TRI[1][1:]),
+         "global_load_dwordx4 v[68:71], v72, s[%s:%s] offset:16" % (TRI[0][1:], TRI[1][1:])]
+    L += ["v_readlane_b32 %s, %s, %d" % (P[i], ST_FIRST, 32 + i) for i in range(10)]
+    L += ["s_mov_b32 s46, 0xb6000000",                                # RT_CULL_P2_SLACK
+          "s_waitcnt vmcnt(0)",
+          "v_subrev_f32 v64, %s, v64" % ox,
+          "v_subrev_f32 v65, %s, v65" % oy,
+          "v_subrev_f32 v66, %s, v66" % oz,
+          "v_mul_f32 v73, v64, v64",
+          "v_fma_f32 v73, v65, v65, v73",
+          "v_fma_f32 v73, v66, v66, v73",                            # vv
+          "v_mul_f32 v74, %s, v64" % ax,
+          "v_fma_f32 v74, %s, v65, v74" % ay,
+          "v_fma_f32 v74, %s, v66, v74" % az,                        # tc
+          "v_fma_f32 v75, -v74, v74, v73",
+          "v_fma_f32 v75, s46, v73, v75",
+          "v_max_f32 v75, 0, v75",
+          "v_sqrt_f32 v75, v75",                                     # p
+          "v_sqrt_f32 v76, v73",                                     # |v|
+          "v_mul_f32 v77, %s, v68" % ax,
+          "v_fma_f32 v77, %s, v69, v77" % ay,
+          "v_fma_f32 v77, %s, v70, v77" % az,
+          "v_sub_f32_e64 v77, |v77|, %s" % ksp,                      # cosn
+          "v_mov_b32 v78, %s" % r0,
+          "v_fma_f32 v78, v67, %s, v78" % k1,
+          "v_fma_f32 v78, %s, v76, v78" % ksp,                       # reach
+          "v_sub_f32 v75, v75, v78",
+          "v_mul_f32 v75, v75, v77",                                 # lhs
+          "v_add_f32 v79, %s, v76" % bw,
+          "v_fma_f32 v79, 4.0, v67, v79",
+          "v_mul_f32 v79, v71, v79",
+          "v_mul_f32 v79, %s, v79" % k1,                             # rhs
+          "v_cmp_gt_f32_e64 %s, v75, v79" % T64,
+          "v_cmp_lt_f32 vcc, 0x3a800000, v77",                       # RT_CULL_GUARD < cosn
+          "s_and_b64 %s, %s, vcc" % (T64, T64),
+          "s_mov_b64 exec, %s" % SURV,
+          "s_bfm_b64 %s, %s, 0" % (SURV, TEND),
+          "s_andn2_b64 %s, %s, %s" % (SURV, SURV, T64),
+          "s_cbranch_scc0 LT_next_%="]
     return L
 
 
@@ -352,20 +419,29 @@ def leaf():
     L = ["LT_leaf_%=:",
          "s_and_b32 %s, %s, 0xff" % (TEND, RMETA),
          "s_cbranch_scc0 LT_next_%=",
-         "s_lshl_b32 %s, %s, 6" % (TCUR, RFIRST),
-         "s_lshl_b32 %s, %s, 6" % (TEND, TEND),
-         "s_add_u32 %s, %s, %s" % (TEND, TEND, TCUR),
-         "s_mov_b64 %s, 0" % CHG,
-         "@PRIO",
-         "LT_leaf_load_%=:",
-         "s_waitcnt lgkmcnt(0)",
-         "s_load_dwordx16 s[%d:%d], s[%s:%s], %s" % (TA, TA + 15, TRI[0][1:], TRI[1][1:], TCUR)]
+         "s_cmp_eq_u32 %s, 0" % CULL,
+         "s_cbranch_scc1 LT_leaf_all_%="]
+    L += cull()
+    L += ["s_branch LT_leaf_open_%=",
+          "LT_leaf_all_%=:",
+          "s_bfm_b64 %s, %s, 0" % (SURV, TEND),
+          "LT_leaf_open_%=:",
+          "s_bitset1_b64 %s, 63" % SURV,
+          "s_mov_b64 %s, 0" % CHG,
+          "@PRIO",
+          "s_ff1_i32_b64 %s, %s" % (JT, SURV),
+          "s_bitset0_b64 %s, %s" % (SURV, JT),
+          "s_add_u32 %s, %s, %s" % (JT, JT, RFIRST),
+          "s_lshl_b32 %s, %s, 6" % (TCUR, JT),
+          "LT_leaf_load_%=:",
+          "s_waitcnt lgkmcnt(0)",
+          "s_load_dwordx16 s[%d:%d], s[%s:%s], %s" % (TA, TA + 15, TRI[0][1:], TRI[1][1:], TCUR)]
     L += triangle(TA, TB, "A", TCUR, TNXT)
-    L += ["s_cmp_lt_u32 %s, %s" % (TNXT, TEND),
-          "s_cbranch_scc0 LT_leaf_done_%="]
+    L += ["s_cmp_eq_u64 %s, 0" % SURV,                                # the record requested meanwhile is the end marker's
+          "s_cbranch_scc1 LT_leaf_done_%="]
     L += triangle(TB, TA, "B", TNXT, TCUR)
-    L += ["s_cmp_lt_u32 %s, %s" % (TCUR, TEND),
-          "s_cbranch_scc1 LT_triA_%=",
+    L += ["s_cmp_eq_u64 %s, 0" % SURV,
+          "s_cbranch_scc0 LT_triA_%=",
           "LT_leaf_done_%=:",
           "s_cmp_eq_u64 %s, 0" % CHG,
           "s_cbranch_scc1 LT_next_%=",
@@ -398,8 +474,11 @@ def block(pattern):
           "s_lshl_b32 %s, %s, 5" % (OFF, IDX),
           "s_load_dwordx8 s[84:91], %s, %s" % (BLK, OFF),
           "s_or_b64 %s, %s, %s" % (CHG, CHG, PASS),
-          "s_cmp_lt_u32 %s, %s" % (TCUR, TEND),
-          "s_cbranch_scc0 LT_leaf_done_%=",
+          "v_readlane_b32 s98, %s, 62" % ST_FIRST,
+          "v_readlane_b32 s99, %s, 63" % ST_FIRST,
+          "s_nop 0",
+          "s_cmp_eq_u64 %s, 0" % SURV,
+          "s_cbranch_scc1 LT_leaf_done_%=",
           "s_branch LT_leaf_load_%=",
           "LT_exit_exact_%=:",
           "s_mov_b32 %s, 1" % RES,
