@@ -69,7 +69,7 @@ __device__ __forceinline__ float wave_min(float v) {
   return __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, fminf(fminf(r0, r1), fminf(r2, r3)))));
 }
 
-// Maximum / sum over the 64 lanes the same way.
+// Maximum over the 64 lanes the same way.
 __device__ __forceinline__ float wave_max(float v) {
   v = fmaxf(v, __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xB1, 0xf, 0xf, true)));
   v = fmaxf(v, __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x4E, 0xf, 0xf, true)));
@@ -79,16 +79,6 @@ __device__ __forceinline__ float wave_max(float v) {
               r2 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 32)), r3 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 48));
   return __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, fmaxf(fmaxf(r0, r1), fmaxf(r2, r3)))));
 }
-__device__ __forceinline__ float wave_sum(float v) {
-  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xB1, 0xf, 0xf, true));
-  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x4E, 0xf, 0xf, true));
-  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x141, 0xf, 0xf, true));
-  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x140, 0xf, 0xf, true));
-  const float r0 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 0)), r1 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 16)),
-              r2 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 32)), r3 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 48));
-  return __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, (r0 + r1) + (r2 + r3))));
-}
-
 // Index of the lane within its wave, derived on the spot (the compiler may not keep the result of a volatile statement
 // for a later use, which is the point: see render_wave).
 __device__ __forceinline__ int fresh_lane_id() {
@@ -107,29 +97,29 @@ __device__ __forceinline__ bool in_mask(uint64_t mask) { return __builtin_amdgcn
 // point light all pass through the light; primary rays share the eye; parallel rays only need some point).  Returns
 // false when the bundle is too wide to rule anything out (rays that have little in common): the walk then tests every
 // triangle as it comes.  All 64 lanes must be active.
-#ifndef RT_CULL_R0_MAX
-#define RT_CULL_R0_MAX 1.0f
-#endif
-#ifndef RT_CULL_KSP_MAX
-#define RT_CULL_KSP_MAX 0.25f
-#endif
-__device__ __forceinline__ bool wave_bundle(uint64_t cls, const RtVec3& e, const RtVec3& d, float stop_t, WaveStack& st) {
+__device__ __forceinline__ bool wave_bundle(uint64_t cls, const RtVec3& e, const RtVec3& d, float stop_t, WaveStack& st, float r0_max, float ksp_max) {
   const bool in = in_mask(cls);
   const float h = stop_t >= 0.f ? fminf(stop_t, RT_INF) : 0.f;
-  const int first = __builtin_ctzll(cls);
-  auto from_first = [&](float v) { return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), first)); };
-  const RtVec3 o = {from_first(fmaf(h, d.x, e.x)), from_first(fmaf(h, d.y, e.y)), from_first(fmaf(h, d.z, e.z))};
-  const RtVec3 sum = {wave_sum(in ? d.x : 0.f), wave_sum(in ? d.y : 0.f), wave_sum(in ? d.z : 0.f)};
-  const float len = rt_len(sum);
-  if (!(len > 0.5f)) return false;   // (directions that cancel: certainly not a bundle)
-  const RtVec3 a = {sum.x / len, sum.y / len, sum.z / len};
-  float r0, bw, k;
-  rt_bundle_lane(o, a, e, d, r0, bw, k);
-  r0 = wave_max(in ? r0 : 0.f); bw = wave_max(in ? bw : 0.f); k = wave_max(in ? k : 0.f);
-  if (!(r0 <= RT_CULL_R0_MAX && k <= RT_CULL_KSP_MAX && bw < 1e6f)) return false;   // (also false for NaN)
+  const int first = __builtin_ctzll(cls), last = 63 - __builtin_clzll(cls);
+  auto from = [&](float v, int lane) { return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), lane)); };
+  const RtVec3 o = {from(fmaf(h, d.x, e.x), first), from(fmaf(h, d.y, e.y), first), from(fmaf(h, d.z, e.z), first)};
+  // axis: between the first and the last ray of the class (opposite corners of a tile); any unit vector would do
+  const RtVec3 sum = {from(d.x, first) + from(d.x, last), from(d.y, first) + from(d.y, last), from(d.z, first) + from(d.z, last)};
+  const float len2 = rt_dot(sum, sum);
+  if (!(len2 > 1.f)) return false;   // (more than 120 degrees apart: certainly not a bundle)
+  const float rl = __builtin_amdgcn_rsqf(len2);   // (the axis is a unit vector to within 2^-21: covered by the slack of rt_bundle_finish)
+  const RtVec3 a = {sum.x * rl, sum.y * rl, sum.z * rl};
+  // rt_bundle_lane on squared lengths (the root is monotone: the largest square belongs to the largest length)
+  const RtVec3 w = {o.x - e.x, o.y - e.y, o.z - e.z};
+  const RtVec3 c = {w.y * d.z - w.z * d.y, w.z * d.x - w.x * d.z, w.x * d.y - w.y * d.x};
+  const RtVec3 q = {d.x - a.x, d.y - a.y, d.z - a.z};
+  const float r0 = __builtin_amdgcn_sqrtf(wave_max(in ? rt_dot(c, c) : 0.f)) * 1.000001f;
+  const float bw = __builtin_amdgcn_sqrtf(wave_max(in ? rt_dot(w, w) : 0.f)) * 1.000001f;
+  const float k = __builtin_amdgcn_sqrtf(wave_max(in ? rt_dot(q, q) : 0.f)) * 1.000001f;
+  if (!(r0 <= r0_max && k <= ksp_max && bw < 1e6f)) return false;   // (also false for NaN)
   const RtBundle B = rt_bundle_finish(o, a, r0, bw, k);
   const float p[10] = {B.ox, B.oy, B.oz, B.ax, B.ay, B.az, B.r0, B.ksp, B.k1, B.bw};
-for (int i = 0; i < 10; i++) st.first = in_mask(1ull << (32 + i)) ? __float_as_uint(p[i]) : st.first;
+  for (int i = 0; i < 10; i++) st.first = in_mask(1ull << (32 + i)) ? __float_as_uint(p[i]) : st.first;
   return true;
 }
 
@@ -224,7 +214,7 @@ template <bool COUNT>
 __device__ __forceinline__ void trace_wave(const float4* __restrict__ nodes, int n_wnodes, const float4* __restrict__ tri_leaf,
                                            const RtSphere* __restrict__ spheres, int n_spheres, bool has_oct, bool want,
                                            const RtVec3& e, const RtVec3& d, float stop_t, Hit& hit, WaveStack& st,
-                                           int lane, Tally& tl, float* cull_lds) {
+                                           int lane, Tally& tl, float* cull_lds, uint32_t cull_offset, float cull_r0_max, float cull_ksp_max) {
   // Lane sets are kept as wave-uniform 64-bit masks in SGPRs (who still has an undecided ray, who entered the
   // current branch, who accepted the current node, ...); they are combined on the scalar unit and only turned
   // back into a per-lane predicate on the rare paths that need one.
@@ -349,7 +339,8 @@ __device__ __forceinline__ void trace_wave(const float4* __restrict__ nodes, int
     // closest hit so far, shadow-ray length), v[60:63] the wave's stack, v32 v33 v35 v36 determinant and numerators
     // of a candidate, v34 v37:v39 v64:v79 scratch.
     if ((presorted || zpat != 0u) && FUSED && (rem & 0xffu) != 0u) {
-      live = walk_asm(nodes, variant, zpat, tri_leaf, top_first, rem, live, e, d, inv, fc, neg_eb, stop_t, hit, st, nullptr, 0u);
+      const uint32_t cull = (cull_offset != 0u && wave_bundle(live, e, d, stop_t, st, cull_r0_max, cull_ksp_max)) ? cull_offset : 0u;
+      live = walk_asm(nodes, variant, zpat, tri_leaf, top_first, rem, live, e, d, inv, fc, neg_eb, stop_t, hit, st, nullptr, cull);
       if (!live) return;
     } else {
 #endif
@@ -812,7 +803,7 @@ __device__ __forceinline__ void trace_wave(const float4* __restrict__ nodes, int
 __device__ __forceinline__ uint64_t trace_class(const float4* __restrict__ nodes, int n_wnodes, const float4* __restrict__ tri_leaf,
                                                 const RtSphere* __restrict__ spheres, int n_spheres, bool has_oct, bool want,
                                                 const RtVec3& e, const RtVec3& d, float stop_t, Hit& hit, WaveStack& st, float* bary_lds,
-                                                uint32_t cull_offset) {
+                                                uint32_t cull_offset, float cull_r0_max, float cull_ksp_max) {
   const uint64_t pending = __builtin_amdgcn_ballot_w64(want);
   if (!pending) return 0ull;
   uint64_t cls = pending, after = pending;
@@ -841,7 +832,7 @@ __device__ __forceinline__ uint64_t trace_class(const float4* __restrict__ nodes
         const f4 ra = *(cnode_ptr)(uintptr_t)vnodes, rb = *((cnode_ptr)(uintptr_t)vnodes + 1);
         neg_eb = -rt_slab_margin_bound_fused(ra.x, ra.y, ra.z, ra.w, rb.x, rb.y, e, inv, fu, hit.t);
       }
-      const uint32_t cull = (cull_offset != 0u && wave_bundle(cls, e, d, stop_t, st)) ? cull_offset : 0u;
+      const uint32_t cull = (cull_offset != 0u && wave_bundle(cls, e, d, stop_t, st, cull_r0_max, cull_ksp_max)) ? cull_offset : 0u;
       after = walk_asm(vnodes, variant, zpat, tri_leaf, top_first, rem, cls, e, d, inv, fu.c, neg_eb, stop_t, hit, st, bary_lds, cull);
     }
   }
@@ -1010,6 +1001,7 @@ struct RtWaveArgs {
   const uint32_t* node_skip;   // links of the stackless walk (trace_lanes)
   int n_spheres, n_lights, has_oct, n_wnodes;
   uint32_t cull_offset, pad_;   // bytes from tri_leaf to its RtCullRec array; 0: the walk tests every triangle (RT_AMD_NO_CULL, measurements)
+  float cull_r0_max, cull_ksp_max;   // widest bundle of a wave's rays that is still put in front of a leaf's triangles (wave_bundle)
   uint8_t* rgb; int32_t* ids; float* ts; unsigned long long* counters_all; int tally;
   // Tiles of the launch and how they are dealt to the chip's dies (see tile_of): tiles per row / column, strips of
   // RT_STRIP_W tile columns per die (0: a plain two-dimensional grid, one workgroup per tile)
@@ -1259,11 +1251,11 @@ __global__ __launch_bounds__(RT_WBLOCK, (BOUNCE && !QPRIMARY) ? RT_WAVES_PER_SIM
       if (LANES) trace_lanes(nodes, LATE(node_skip), tri_leaf, spheres, n_spheres, has_oct != 0, want, tr_e, tr_d, stop_t, h);
       else if (CLASSES) {
         float* const bary = parked + (SW + 4) * RT_WBLOCK + (RT_WBLOCK == 64 ? 0 : (TID() & ~63));   // the wave's columns of the two barycentric words
-        traced = in_mask(trace_class(nodes, n_wnodes, tri_leaf, spheres, n_spheres, has_oct != 0, want, tr_e, tr_d, stop_t, h, st, bary, LATE(cull_offset)));
+        traced = in_mask(trace_class(nodes, n_wnodes, tri_leaf, spheres, n_spheres, has_oct != 0, want, tr_e, tr_d, stop_t, h, st, bary, LATE(cull_offset), LATE(cull_r0_max), LATE(cull_ksp_max)));
         asm volatile("" ::: "memory");
         h.bet = bary[LANE()]; h.gam = bary[RT_WBLOCK + LANE()];   // (only meaningful, and only used, when a triangle was hit)
       }
-      else trace_wave<COUNT>(nodes, n_wnodes, tri_leaf, spheres, n_spheres, has_oct != 0, want, tr_e, tr_d, stop_t, h, st, LANE(), tl, cull_sh + 16 * (TID() >> 6));
+      else trace_wave<COUNT>(nodes, n_wnodes, tri_leaf, spheres, n_spheres, has_oct != 0, want, tr_e, tr_d, stop_t, h, st, LANE(), tl, cull_sh + 16 * (TID() >> 6), COUNT ? 0u : LATE(cull_offset), LATE(cull_r0_max), LATE(cull_ksp_max));
       asm volatile("" ::: "memory");
       unpark<BOUNCE, TEX, QPRIMARY>(sh, MY_PARK());
     }
@@ -1562,7 +1554,14 @@ void rt_launch_wave_kernel(const RtDeviceView& V, const RowMap& rows, bool bounc
   A.tri_uv = V.tri_uv; A.textures = V.textures; A.texels = V.texels; A.node_skip = V.node_skip;
   A.n_spheres = V.n_spheres; A.n_lights = V.n_lights; A.has_oct = V.has_oct; A.n_wnodes = V.n_wnodes;
   static const bool no_cull = getenv("RT_AMD_NO_CULL") != nullptr;
-  A.cull_offset = no_cull ? 0u : V.cull_offset; A.pad_ = 0u;
+  // (small meshes: what a wave saves in their few leaves does not pay for working out its bundle - boxedSpheres, 12 triangles: + 16 %;
+  //  rays from the queues: scattered by construction, their bundles rule nothing out)
+  static const int cull_min_nodes = getenv("RT_AMD_CULL_MIN_NODES") ? atoi(getenv("RT_AMD_CULL_MIN_NODES")) : 512;
+  static const bool cull_queued = getenv("RT_AMD_CULL_QUEUED") != nullptr;
+  A.cull_offset = (no_cull || V.n_wnodes < cull_min_nodes || (wf.in && !cull_queued)) ? 0u : V.cull_offset; A.pad_ = 0u;
+  static const float cull_r0 = getenv("RT_AMD_CULL_R0") ? (float)atof(getenv("RT_AMD_CULL_R0")) : 1.0f;      // measurements
+  static const float cull_ksp = getenv("RT_AMD_CULL_KSP") ? (float)atof(getenv("RT_AMD_CULL_KSP")) : 0.25f;
+  A.cull_r0_max = cull_r0; A.cull_ksp_max = cull_ksp;
   A.rgb = rgb; A.ids = ids; A.ts = ts; A.counters_all = counters; A.tally = tally ? 1 : 0; A.wf = wf;
 #define LAUNCH(B, C, Q) hipLaunchKernelGGL((render_wave<B, C, Q>), grid, block, 0, stream, V.wnodes, V.tri_leaf, A)
   if (V.textures) {   // (never from queues: rt_device.hip keeps scenes with texture materials on the stacks)

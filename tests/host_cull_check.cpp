@@ -24,8 +24,8 @@ static uint64_t n_pairs = 0, n_skip = 0, n_bad = 0, n_accept = 0;
 struct Ray { RtVec3 e, d; };
 
 static RtBundle bundle_of(const std::vector<Ray>& rays, const RtVec3& o) {
-  RtVec3 s = {0, 0, 0};
-  for (const Ray& r : rays) { s.x += r.d.x; s.y += r.d.y; s.z += r.d.z; }
+  // (the kernel's axis: between the first and the last ray)
+  const RtVec3 s = {rays.front().d.x + rays.back().d.x, rays.front().d.y + rays.back().d.y, rays.front().d.z + rays.back().d.z};
   const RtVec3 a = rt_normalized(s);
   float r0 = 0, bw = 0, k = 0;
   for (const Ray& r : rays) { float x, y, z; rt_bundle_lane(o, a, r.e, r.d, x, y, z); r0 = fmaxf(r0, x); bw = fmaxf(bw, y); k = fmaxf(k, z); }

@@ -28,7 +28,7 @@ TCUR, TNXT, TEND = "s20", "s21", "s22"
 # The mask starts as the triangles that the wave's bundle of rays can possibly be accepted by (cull(): lane k looks at
 # triangle k of the leaf; rt_cull_test in rt_math.h), or as all of them when the caller passes no bundle (CULL = 0).
 # Outside the block the mask waits in lanes 62 / 63 of the stack register ST_FIRST, whose lanes 32 .. 41 hold the bundle.
-SURV, JT = "s[98:99]", "s22"       # (SURV shares the registers of NR, which only lives within the scan; TEND only carries the leaf's triangle count into the mask; then it is the scratch index JT)
+SURV, JT = "s[98:99]", "s22"       # (SURV shares the registers of NR, which only lives within the scan; in such a leaf TEND only carries the triangle count into the mask and is the scratch index JT afterwards)
 CULL = "s19"                     # byte offset of the RtCullRec array from the triangle records, 0: test every triangle
 CHG, T64, PASS = "s[24:25]", "s[26:27]", "s[28:29]"
 RES, RPRIM = "s30", "s31"
@@ -280,9 +280,10 @@ def scan_zero(pattern):
     return L
 
 
-def triangle(q, other, tag, cur, nxt):
-    """The numerator stages on the record in s[q : q+15] (at offset `cur`); midway the record behind it (offset `nxt` = `cur` + 64)
-    is requested into s[other : other+15]."""
+def triangle(q, other, tag, cur, nxt, masked):
+    """The numerator stages on the record in s[q : q+15] (at offset `cur`); midway the next record to be tested (offset `nxt`) is
+    requested into s[other : other+15]: the one behind it (`cur` + 64) in a leaf walked from end to end, the one of the lowest bit
+    left in SURV in a leaf whose triangles were put in front of the wave's bundle first (masked)."""
     bxy, bz = "v[68:69]", "v74"
     bx, by = "v68", "v69"
     det, nb, nbs, ng, nt, sg = "v32", "v33", "v34", "v35", "v36", "v39"
@@ -300,10 +301,7 @@ def triangle(q, other, tag, cur, nxt):
          "v_pk_mul_f32 v[78:79], %s, v[70:71]" % bxy,                                           # b.x m00 , b.y m10
          "v_add_f32 v76, v76, v77",
          "v_mul_f32 v77, %s, v75" % s(q + 6),                                                   # e1.z m20
-         "s_ff1_i32_b64 %s, %s" % (JT, SURV),
-         "s_bitset0_b64 %s, %s" % (SURV, JT),
-         "s_add_u32 %s, %s, %s" % (JT, JT, RFIRST),
-         "s_lshl_b32 %s, %s, 6" % (nxt, JT),
+         "@NEXT",
          "s_load_dwordx16 s[%d:%d], s[%s:%s], %s" % (other, other + 15, TRI[0][1:], TRI[1][1:], nxt),
          "v_add_f32 %s, v76, v77" % det,
          "v_add_f32 v78, v78, v79",
@@ -352,12 +350,20 @@ def triangle(q, other, tag, cur, nxt):
          # candidates: the quotients are formed outside; the walk goes on behind this record
          "s_mov_b32 %s, %s" % (RPRIM, s(q + 3)),
          "s_mov_b32 %s, %s" % (TCUR, nxt),                                                       # where the leaf goes on afterwards
-         "v_writelane_b32 %s, s98, 62" % ST_FIRST,
-         "v_writelane_b32 %s, s99, 63" % ST_FIRST,
+         "@SAVE",
          "s_mov_b32 %s, 2" % RES,
          "s_branch LT_out_%=",
          "LT_end%s_%%=:" % tag]
-    return L
+    out = []
+    for line in L:
+        if line == "@NEXT":
+            out += (["s_ff1_i32_b64 %s, %s" % (JT, SURV), "s_bitset0_b64 %s, %s" % (SURV, JT), "s_add_u32 %s, %s, %s" % (JT, JT, RFIRST),
+                     "s_lshl_b32 %s, %s, 6" % (nxt, JT)] if masked else ["s_add_u32 %s, %s, 0x40" % (nxt, cur)])
+        elif line == "@SAVE":
+            out += ["v_writelane_b32 %s, s98, 62" % ST_FIRST, "v_writelane_b32 %s, s99, 63" % ST_FIRST] if masked else []
+        else:
+            out.append(line)
+    return out
 
 
 def cull():
@@ -421,12 +427,9 @@ def leaf():
          "s_cbranch_scc0 LT_next_%=",
          "s_cmp_eq_u32 %s, 0" % CULL,
          "s_cbranch_scc1 LT_leaf_all_%="]
+    # ---- with a bundle: the triangles that survive it, lowest bit first
     L += cull()
-    L += ["s_branch LT_leaf_open_%=",
-          "LT_leaf_all_%=:",
-          "s_bfm_b64 %s, %s, 0" % (SURV, TEND),
-          "LT_leaf_open_%=:",
-          "s_bitset1_b64 %s, 63" % SURV,
+    L += ["s_bitset1_b64 %s, 63" % SURV,
           "s_mov_b64 %s, 0" % CHG,
           "@PRIO",
           "s_ff1_i32_b64 %s, %s" % (JT, SURV),
@@ -436,12 +439,29 @@ def leaf():
           "LT_leaf_load_%=:",
           "s_waitcnt lgkmcnt(0)",
           "s_load_dwordx16 s[%d:%d], s[%s:%s], %s" % (TA, TA + 15, TRI[0][1:], TRI[1][1:], TCUR)]
-    L += triangle(TA, TB, "A", TCUR, TNXT)
+    L += triangle(TA, TB, "A", TCUR, TNXT, True)
     L += ["s_cmp_eq_u64 %s, 0" % SURV,                                # the record requested meanwhile is the end marker's
           "s_cbranch_scc1 LT_leaf_done_%="]
-    L += triangle(TB, TA, "B", TNXT, TCUR)
+    L += triangle(TB, TA, "B", TNXT, TCUR, True)
     L += ["s_cmp_eq_u64 %s, 0" % SURV,
           "s_cbranch_scc0 LT_triA_%=",
+          "s_branch LT_leaf_done_%=",
+          # ---- without: every triangle of the leaf, one record after the other
+          "LT_leaf_all_%=:",
+          "s_lshl_b32 %s, %s, 6" % (TCUR, RFIRST),
+          "s_lshl_b32 %s, %s, 6" % (TEND, TEND),
+          "s_add_u32 %s, %s, %s" % (TEND, TEND, TCUR),
+          "s_mov_b64 %s, 0" % CHG,
+          "@PRIO",
+          "LT_leaf_load_all_%=:",
+          "s_waitcnt lgkmcnt(0)",
+          "s_load_dwordx16 s[%d:%d], s[%s:%s], %s" % (TA, TA + 15, TRI[0][1:], TRI[1][1:], TCUR)]
+    L += triangle(TA, TB, "C", TCUR, TNXT, False)
+    L += ["s_cmp_lt_u32 %s, %s" % (TNXT, TEND),
+          "s_cbranch_scc0 LT_leaf_done_%="]
+    L += triangle(TB, TA, "D", TNXT, TCUR, False)
+    L += ["s_cmp_lt_u32 %s, %s" % (TCUR, TEND),
+          "s_cbranch_scc1 LT_triC_%=",
           "LT_leaf_done_%=:",
           "s_cmp_eq_u64 %s, 0" % CHG,
           "s_cbranch_scc1 LT_next_%=",
@@ -474,12 +494,18 @@ def block(pattern):
           "s_lshl_b32 %s, %s, 5" % (OFF, IDX),
           "s_load_dwordx8 s[84:91], %s, %s" % (BLK, OFF),
           "s_or_b64 %s, %s, %s" % (CHG, CHG, PASS),
+          "s_cmp_eq_u32 %s, 0" % CULL,
+          "s_cbranch_scc1 LT_resume_all_%=",
           "v_readlane_b32 s98, %s, 62" % ST_FIRST,
           "v_readlane_b32 s99, %s, 63" % ST_FIRST,
           "s_nop 0",
           "s_cmp_eq_u64 %s, 0" % SURV,
           "s_cbranch_scc1 LT_leaf_done_%=",
           "s_branch LT_leaf_load_%=",
+          "LT_resume_all_%=:",
+          "s_cmp_lt_u32 %s, %s" % (TCUR, TEND),
+          "s_cbranch_scc0 LT_leaf_done_%=",
+          "s_branch LT_leaf_load_all_%=",
           "LT_exit_exact_%=:",
           "s_mov_b32 %s, 1" % RES,
           "s_branch LT_out_%=",
