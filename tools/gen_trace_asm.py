@@ -426,7 +426,8 @@ def leaf():
          "s_and_b32 %s, %s, 0xff" % (TEND, RMETA),
          "s_cbranch_scc0 LT_next_%=",
          "s_cmp_eq_u32 %s, 0" % CULL,
-         "s_cbranch_scc1 LT_leaf_all_%="]
+         "s_cbranch_scc1 LT_leaf_all_%=",
+         "@MINTRIS"]
     # ---- with a bundle: the triangles that survive it, lowest bit first
     L += cull()
     L += ["s_bitset1_b64 %s, 63" % SURV,
@@ -528,7 +529,7 @@ def main():
             L += ["s_cmp_eq_u32 s18, %d" % pattern, "s_cbranch_scc1 LT%d_begin_%%=" % pattern]
         for pattern in range(7):
             B = ["LT%d_begin_%%=:" % pattern] + block(pattern) + ["s_branch LT_end_all_%="]
-            L += [line.replace("LT_", "LT%d_" % pattern) if "LT_end_all" not in line else line for line in B]
+            L += [("LT%d_@MINTRIS" % pattern if line == "@MINTRIS" else line.replace("LT_", "LT%d_" % pattern)) if "LT_end_all" not in line else line for line in B]
             print("pattern", pattern, len(B), "lines")
         L += ["LT_end_all_%=:"]
         # Measurement builds (-DRT_WALK_PRIO=k): a wave counts the leaves it enters (s23, zeroed by the caller) and raises its issue
@@ -539,8 +540,18 @@ def main():
                 "  \"s_bitcmp1_b32 s23, \" RT_PRIO_STR(RT_WALK_PRIO) \"+1\\n\" \"s_cbranch_scc0 1\\n\" \"s_setprio 2\\n\" \\\n"
                 "  \"s_bitcmp1_b32 s23, \" RT_PRIO_STR(RT_WALK_PRIO) \"+2\\n\" \"s_cbranch_scc0 1\\n\" \"s_setprio 3\\n\"\n"
                 "#else\n#define RT_PRIO_STEP \"\"\n#endif\n")
+        # A leaf with fewer than RT_CULL_MIN_TRIS triangles is walked from end to end even when there is a bundle (asking costs about
+        # as much as two and a half triangle tests).
+        f.write("#ifndef RT_CULL_MIN_TRIS\n#define RT_CULL_MIN_TRIS 3\n#endif\n#define RT_MINTRIS_STR2(x) #x\n#define RT_MINTRIS_STR(x) RT_MINTRIS_STR2(x)\n")
         f.write("#define RT_TRACE_ASM \\\n")
-        f.write(" \\\n".join(('RT_PRIO_STEP' if line == "@PRIO" else '"%s\\n"' % line) for line in L))
+        def emit(line):
+            if line == "@PRIO":
+                return 'RT_PRIO_STEP'
+            if "@MINTRIS" in line:
+                pat = line.split("@MINTRIS")[0]
+                return '"s_cmp_lt_u32 %s, " RT_MINTRIS_STR(RT_CULL_MIN_TRIS) "\\n" "s_cbranch_scc1 %sleaf_all_%%=\\n"' % (TEND, pat)
+            return '"%s\\n"' % line
+        f.write(" \\\n".join(emit(line) for line in L))
         f.write("\n")
     print("wrote", os.path.normpath(out))
 
