@@ -839,6 +839,15 @@ void load_scene_into(rt_scene& sc, const std::string& scene_path, const std::str
         }
         meta = 0x80000000u | occupied;
       }
+      // Is the bundle test worth its price in this leaf?  Not for a couple of triangles, and not where most triangles are
+      // large against the leaf (their bounding balls reach every ray that enters the cube) or cannot be ruled out at all.
+      if (count >= RT_LEAF_ASK_MIN) {
+        const RtCullRec* const cull = reinterpret_cast<const RtCullRec*>(reinterpret_cast<const char*>(sc.tri_leaf.data()) + sc.cull_offset);
+        const float side = hi[0] - lo[0];
+        int32_t compact = 0;
+        for (int32_t r = first; r < first + count; r++) if (std::isfinite(cull[r].Q) && cull[r].R <= side) compact++;
+        if (2 * compact >= count) meta |= RT_LEAF_ASK;
+      }
       meta |= (uint32_t)sibling[i] << 24;
       for (int v = 0; v < RT_NODE_VARIANTS; v++) {
         RtWaveNode& w = sc.wnodes[(size_t)v * sc.nodes.size() + i];

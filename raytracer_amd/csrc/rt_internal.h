@@ -15,6 +15,8 @@
 #define RT_NEAR 0.1f
 #define RT_LEAF_CAP 50
 #define RT_LEAF_PAD 64   // records behind the last leaf's that a walk may still request
+#define RT_LEAF_ASK 0x100u   // bit of a leaf's RtWaveNode::meta, see there
+#define RT_LEAF_ASK_MIN 3    // fewest triangles of a leaf worth asking about (asking costs about as much as two and a half triangle tests)
 #define RT_RAY_STACK 10
 #define RT_OCT_STACK 20
 #define RT_MAX_LEVELS 3
@@ -62,8 +64,9 @@ struct RtNode { float a[4]; float b[4]; };
 // The same node as the wave-synchronous kernel reads it, 32 B = one 8-dword scalar load.  The two planes of an
 // axis sit in adjacent dwords so that a packed-fp32 instruction can take them straight from an SGPR pair.
 //   p.x q.x p.y q.y | p.z q.z first meta
-//   meta: leaf -> number of triangles (0..50); branch -> 0x80000000 | bit c set when child c is not an empty leaf;
-//         either way bits 24..26 hold the record's own position among its eight siblings (0 for the root)
+//   meta: leaf -> number of triangles (0..50), | RT_LEAF_ASK when a wave had better put its bundle of rays in front of the
+//         leaf's triangles before testing them (rt_math.h, rt_cull_test); branch -> 0x80000000 | bit c set when child c is
+//         not an empty leaf; either way bits 24..26 hold the record's own position among its eight siblings (0 for the root)
 // The array is stored RT_NODE_VARIANTS = 8 times over (variant v of node i is record v * n + i, n counting the pad
 // record, so that a walk stays inside one dense copy):  in variant v the pair of axis k is
 // (lo, hi) when bit k of v is clear and (hi, lo) when it is set, lo / hi being the min / max corner

@@ -97,7 +97,7 @@ __device__ __forceinline__ bool in_mask(uint64_t mask) { return __builtin_amdgcn
 // point light all pass through the light; primary rays share the eye; parallel rays only need some point).  Returns
 // false when the bundle is too wide to rule anything out (rays that have little in common): the walk then tests every
 // triangle as it comes.  All 64 lanes must be active.
-__device__ __forceinline__ bool wave_bundle(uint64_t cls, const RtVec3& e, const RtVec3& d, float stop_t, WaveStack& st, float r0_max, float ksp_max) {
+__device__ __forceinline__ bool wave_bundle(uint64_t cls, const RtVec3& e, const RtVec3& d, float stop_t, RtBundle& out, float r0_max, float ksp_max) {
   const bool in = in_mask(cls);
   const float h = stop_t >= 0.f ? fminf(stop_t, RT_INF) : 0.f;
   const int first = __builtin_ctzll(cls), last = 63 - __builtin_clzll(cls);
@@ -117,9 +117,7 @@ __device__ __forceinline__ bool wave_bundle(uint64_t cls, const RtVec3& e, const
   const float bw = __builtin_amdgcn_sqrtf(wave_max(in ? rt_dot(w, w) : 0.f)) * 1.000001f;
   const float k = __builtin_amdgcn_sqrtf(wave_max(in ? rt_dot(q, q) : 0.f)) * 1.000001f;
   if (!(r0 <= r0_max && k <= ksp_max && bw < 1e6f)) return false;   // (also false for NaN)
-  const RtBundle B = rt_bundle_finish(o, a, r0, bw, k);
-  const float p[10] = {B.ox, B.oy, B.oz, B.ax, B.ay, B.az, B.r0, B.ksp, B.k1, B.bw};
-  for (int i = 0; i < 10; i++) st.first = in_mask(1ull << (32 + i)) ? __float_as_uint(p[i]) : st.first;
+  out = rt_bundle_finish(o, a, r0, bw, k);
   return true;
 }
 
@@ -131,13 +129,19 @@ __device__ __forceinline__ bool wave_bundle(uint64_t cls, const RtVec3& e, const
 // bary_lds != nullptr: the barycentrics of an accepted triangle go to LDS (word 0 and word RT_WBLOCK of the lane's column
 // there) instead of into `hit` - they change a few times per walk and are read once per closest hit, and as part of `hit`
 // they would be carried through the whole walk in two registers.
-// cull != 0: byte offset of the RtCullRec array behind the triangle records, and lanes 32 .. 41 of st.first hold the
-// bundle of the rays in `live` (wave_bundle): on entering a leaf the walk leaves out the triangles that no ray of the
-// bundle can be accepted by.  cull == 0: every triangle of every leaf entered is tested.
+// CULL, cull != 0: `cull` is the byte offset of the RtCullRec array behind the triangle records and `bundle` the bundle of the
+// rays in `live` (wave_bundle): on entering a leaf the walk leaves out the triangles that no ray of the bundle can be
+// accepted by.  cull == 0, or the variant of the block without that code (!CULL: kernels whose rays never form a
+// bundle): every triangle of every leaf entered is tested.
+template <bool CULL>
 __device__ __forceinline__ uint64_t walk_asm(const float4* nodes, uint32_t variant, uint32_t zpat, const float4* tri_leaf, uint32_t top_first, uint32_t rem,
                                              uint64_t live, const RtVec3& e, const RtVec3& d, const RtVec3& inv, const RtVec3& fc, float neg_eb,
-                                             float stop_t, Hit& hit, WaveStack& st, float* bary_lds, uint32_t cull) {
-  const RtVec3 c2 = {-d.x, -d.y, -d.z};                   // third column of the triangle solve (triangle.cu:118-120)
+                                             float stop_t, Hit& hit, WaveStack& st, float* bary_lds, uint32_t cull, const RtBundle& bundle) {
+  const RtVec3 c2 = {-d.x, -d.y, -d.z};
+  // (wave-uniform values, pinned to scalar registers once: the walk reads them on every leaf it enters)
+  const uint32_t b0 = uni(__float_as_uint(bundle.ox)), b1 = uni(__float_as_uint(bundle.oy)), b2 = uni(__float_as_uint(bundle.oz)), b3 = uni(__float_as_uint(bundle.ax)),
+                 b4 = uni(__float_as_uint(bundle.ay)), b5 = uni(__float_as_uint(bundle.az)), b6 = uni(__float_as_uint(bundle.r0)), b7 = uni(__float_as_uint(bundle.ksp)),
+                 b8 = uni(__float_as_uint(bundle.k1)), b9 = uni(__float_as_uint(bundle.bw));                   // third column of the triangle solve (triangle.cu:118-120)
   const v2f e_xy = {e.x, e.y}, c_zx = {c2.z, c2.x}, c_yz = {c2.y, c2.z}, c_yx = {c2.y, c2.x};
   uint64_t a_blk = (uint64_t)(uintptr_t)(nodes + 2 * (size_t)top_first);
   uint32_t a_rem = rem | 0x100u, a_first = top_first, a_idx = 0u, a_rfirst = 0u, a_rmeta = 0u, a_tcur = 0u, a_tend = 0u, a_res = 0u, a_prim = 0u, a_sp = 0u;
@@ -154,19 +158,36 @@ __device__ __forceinline__ uint64_t walk_asm(const float4* nodes, uint32_t varia
   // (one copy of the block per kind of node test inside the one statement: sign-uniform rays (0), or the rays' common
   //  zero pattern (1..6), chosen by s18)
   for (;;) {
-    asm volatile(RT_TRACE_ASM
-        : "+{s[68:69]}"(a_blk), "+{s70}"(a_rem), "+{s71}"(a_first), "+{s[72:73]}"(a_tmask), "+{s[74:75]}"(a_mine), "+{s[76:77]}"(a_live),
-          "+{s78}"(a_idx), "+{s79}"(a_rfirst), "+{s80}"(a_rmeta), "+{s[94:95]}"(a_acc), "+{s[96:97]}"(a_und), "+{s[28:29]}"(a_pass),
-          "+{s20}"(a_tcur), "+{s22}"(a_tend), "+{s[24:25]}"(a_chg), "+{s30}"(a_res), "+{s31}"(a_prim), "+{m0}"(a_sp) RT_PRIO_OPERAND,
-          "+{v60}"(st.first), "+{v61}"(st.cur), "+{v62}"(st.mask_lo), "+{v63}"(st.mask_hi),
-          "={v32}"(a_det), "={v33}"(a_nb), "={v35}"(a_ng), "={v36}"(a_nt)
-        : "{s[82:83]}"(a_nodes), "{s[92:93]}"(a_tri), "{s18}"(zpat), "{s19}"(cull), "{v[40:41]}"(e_xy), "{v42}"(e.z), "{v[44:45]}"(c_zx), "{v[46:47]}"(c_yz),
-          "{v[48:49]}"(c_yx), "{v50}"(inv.x), "{v51}"(inv.y), "{v52}"(inv.z), "{v53}"(fc.x), "{v54}"(fc.y), "{v55}"(fc.z), "{v56}"(cmax),
-          "{v57}"(neg_eb), "{v58}"(hit.t), "{v59}"(stop_t)
-        : "s36", "s37", "s38", "s39", "s40", "s41", "s42", "s43", "s44", "s45", "s46", "s47", "s48", "s49", "s50", "s51", "s52", "s53", "s54", "s55",
-          "s56", "s57", "s58", "s59", "s60", "s61", "s62", "s63", "s64", "s65", "s66", "s67", "s81", "s84", "s85", "s86", "s87", "s88", "s89", "s90",
-          "s91", "s98", "s99", "s26", "s27", "s21", "v34", "v37", "v38", "v39", "v64", "v65", "v66", "v67", "v68", "v69", "v70", "v71", "v72", "v73", "v74",
-          "v75", "v76", "v77", "v78", "v79", "vcc", "scc");
+    if constexpr (CULL) {
+      asm volatile(RT_TRACE_ASM_CULL
+          : "+{s[68:69]}"(a_blk), "+{s70}"(a_rem), "+{s71}"(a_first), "+{s[72:73]}"(a_tmask), "+{s[74:75]}"(a_mine), "+{s[76:77]}"(a_live),
+            "+{s78}"(a_idx), "+{s79}"(a_rfirst), "+{s80}"(a_rmeta), "+{s[94:95]}"(a_acc), "+{s[96:97]}"(a_und), "+{s[28:29]}"(a_pass),
+            "+{s20}"(a_tcur), "+{s22}"(a_tend), "+{s[24:25]}"(a_chg), "+{s30}"(a_res), "+{s31}"(a_prim), "+{m0}"(a_sp) RT_PRIO_OPERAND,
+            "+{v60}"(st.first), "+{v61}"(st.cur), "+{v62}"(st.mask_lo), "+{v63}"(st.mask_hi),
+            "={v32}"(a_det), "={v33}"(a_nb), "={v35}"(a_ng), "={v36}"(a_nt)
+          : "{s[82:83]}"(a_nodes), "{s[92:93]}"(a_tri), "{s18}"(zpat), "{s19}"(cull), "{v[40:41]}"(e_xy), "{v42}"(e.z), "{v[44:45]}"(c_zx), "{v[46:47]}"(c_yz),
+            "{v[48:49]}"(c_yx), "{v50}"(inv.x), "{v51}"(inv.y), "{v52}"(inv.z), "{v53}"(fc.x), "{v54}"(fc.y), "{v55}"(fc.z), "{v56}"(cmax),
+            "{v57}"(neg_eb), "{v58}"(hit.t), "{v59}"(stop_t),
+            [b0] "s"(b0), [b1] "s"(b1), [b2] "s"(b2), [b3] "s"(b3), [b4] "s"(b4), [b5] "s"(b5), [b6] "s"(b6), [b7] "s"(b7), [b8] "s"(b8), [b9] "s"(b9)
+          : "s36", "s37", "s38", "s39", "s40", "s41", "s42", "s43", "s44", "s45", "s46", "s47", "s48", "s49", "s50", "s51", "s52", "s53", "s54", "s55",
+            "s56", "s57", "s58", "s59", "s60", "s61", "s62", "s63", "s64", "s65", "s66", "s67", "s81", "s84", "s85", "s86", "s87", "s88", "s89", "s90",
+            "s91", "s98", "s99", "s26", "s27", "s21", "v34", "v37", "v38", "v39", "v64", "v65", "v66", "v67", "v68", "v69", "v70", "v71", "v72", "v73", "v74",
+            "v75", "v76", "v77", "v78", "v79", "vcc", "scc");
+    } else {
+      asm volatile(RT_TRACE_ASM_PLAIN
+          : "+{s[68:69]}"(a_blk), "+{s70}"(a_rem), "+{s71}"(a_first), "+{s[72:73]}"(a_tmask), "+{s[74:75]}"(a_mine), "+{s[76:77]}"(a_live),
+            "+{s78}"(a_idx), "+{s79}"(a_rfirst), "+{s80}"(a_rmeta), "+{s[94:95]}"(a_acc), "+{s[96:97]}"(a_und), "+{s[28:29]}"(a_pass),
+            "+{s20}"(a_tcur), "+{s22}"(a_tend), "+{s[24:25]}"(a_chg), "+{s30}"(a_res), "+{s31}"(a_prim), "+{m0}"(a_sp) RT_PRIO_OPERAND,
+            "+{v60}"(st.first), "+{v61}"(st.cur), "+{v62}"(st.mask_lo), "+{v63}"(st.mask_hi),
+            "={v32}"(a_det), "={v33}"(a_nb), "={v35}"(a_ng), "={v36}"(a_nt)
+          : "{s[82:83]}"(a_nodes), "{s[92:93]}"(a_tri), "{s18}"(zpat), "{v[40:41]}"(e_xy), "{v42}"(e.z), "{v[44:45]}"(c_zx), "{v[46:47]}"(c_yz),
+            "{v[48:49]}"(c_yx), "{v50}"(inv.x), "{v51}"(inv.y), "{v52}"(inv.z), "{v53}"(fc.x), "{v54}"(fc.y), "{v55}"(fc.z), "{v56}"(cmax),
+            "{v57}"(neg_eb), "{v58}"(hit.t), "{v59}"(stop_t)
+          : "s36", "s37", "s38", "s39", "s40", "s41", "s42", "s43", "s44", "s45", "s46", "s47", "s48", "s49", "s50", "s51", "s52", "s53", "s54", "s55",
+            "s56", "s57", "s58", "s59", "s60", "s61", "s62", "s63", "s64", "s65", "s66", "s67", "s81", "s84", "s85", "s86", "s87", "s88", "s89", "s90",
+            "s91", "s98", "s99", "s26", "s27", "s21", "v34", "v37", "v38", "v39", "v64", "v65", "v66", "v67", "v68", "v69", "v70", "v71", "v72", "v73", "v74",
+            "v75", "v76", "v77", "v78", "v79", "vcc", "scc");
+    }
     if (a_res == 0u) break;
     if (a_res == 1u) {
       // the exact test for the lanes in a_und: the planes of the child just tested are read again
@@ -210,7 +231,7 @@ __device__ __forceinline__ uint64_t walk_asm(const float4* nodes, uint32_t varia
 //   want   : this lane has a ray to trace
 //   stop_t : >= 0 for a shadow ray: the lane drops out as soon as its t falls below stop_t, because
 //            only "t < light distance" is consumed (ray.cu:70) and t never grows; < 0 = never
-template <bool COUNT>
+template <bool COUNT, bool CULLABLE>
 __device__ __forceinline__ void trace_wave(const float4* __restrict__ nodes, int n_wnodes, const float4* __restrict__ tri_leaf,
                                            const RtSphere* __restrict__ spheres, int n_spheres, bool has_oct, bool want,
                                            const RtVec3& e, const RtVec3& d, float stop_t, Hit& hit, WaveStack& st,
@@ -339,8 +360,9 @@ __device__ __forceinline__ void trace_wave(const float4* __restrict__ nodes, int
     // closest hit so far, shadow-ray length), v[60:63] the wave's stack, v32 v33 v35 v36 determinant and numerators
     // of a candidate, v34 v37:v39 v64:v79 scratch.
     if ((presorted || zpat != 0u) && FUSED && (rem & 0xffu) != 0u) {
-      const uint32_t cull = (cull_offset != 0u && wave_bundle(live, e, d, stop_t, st, cull_r0_max, cull_ksp_max)) ? cull_offset : 0u;
-      live = walk_asm(nodes, variant, zpat, tri_leaf, top_first, rem, live, e, d, inv, fc, neg_eb, stop_t, hit, st, nullptr, cull);
+      RtBundle bundle = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+      const uint32_t cull = (CULLABLE && cull_offset != 0u && wave_bundle(live, e, d, stop_t, bundle, cull_r0_max, cull_ksp_max)) ? cull_offset : 0u;
+      live = walk_asm<CULLABLE>(nodes, variant, zpat, tri_leaf, top_first, rem, live, e, d, inv, fc, neg_eb, stop_t, hit, st, nullptr, cull, bundle);
       if (!live) return;
     } else {
 #endif
@@ -832,8 +854,9 @@ __device__ __forceinline__ uint64_t trace_class(const float4* __restrict__ nodes
         const f4 ra = *(cnode_ptr)(uintptr_t)vnodes, rb = *((cnode_ptr)(uintptr_t)vnodes + 1);
         neg_eb = -rt_slab_margin_bound_fused(ra.x, ra.y, ra.z, ra.w, rb.x, rb.y, e, inv, fu, hit.t);
       }
-      const uint32_t cull = (cull_offset != 0u && wave_bundle(cls, e, d, stop_t, st, cull_r0_max, cull_ksp_max)) ? cull_offset : 0u;
-      after = walk_asm(vnodes, variant, zpat, tri_leaf, top_first, rem, cls, e, d, inv, fu.c, neg_eb, stop_t, hit, st, bary_lds, cull);
+      RtBundle bundle = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+      const uint32_t cull = (cull_offset != 0u && wave_bundle(cls, e, d, stop_t, bundle, cull_r0_max, cull_ksp_max)) ? cull_offset : 0u;
+      after = walk_asm<true>(vnodes, variant, zpat, tri_leaf, top_first, rem, cls, e, d, inv, fu.c, neg_eb, stop_t, hit, st, bary_lds, cull, bundle);
     }
   }
   if (n_spheres > 0 && after) {
@@ -1255,7 +1278,7 @@ __global__ __launch_bounds__(RT_WBLOCK, (BOUNCE && !QPRIMARY) ? RT_WAVES_PER_SIM
         asm volatile("" ::: "memory");
         h.bet = bary[LANE()]; h.gam = bary[RT_WBLOCK + LANE()];   // (only meaningful, and only used, when a triangle was hit)
       }
-      else trace_wave<COUNT>(nodes, n_wnodes, tri_leaf, spheres, n_spheres, has_oct != 0, want, tr_e, tr_d, stop_t, h, st, LANE(), tl, cull_sh + 16 * (TID() >> 6), COUNT ? 0u : LATE(cull_offset), LATE(cull_r0_max), LATE(cull_ksp_max));
+      else trace_wave<COUNT, !queued && !COUNT>(nodes, n_wnodes, tri_leaf, spheres, n_spheres, has_oct != 0, want, tr_e, tr_d, stop_t, h, st, LANE(), tl, cull_sh + 16 * (TID() >> 6), COUNT ? 0u : LATE(cull_offset), LATE(cull_r0_max), LATE(cull_ksp_max));
       asm volatile("" ::: "memory");
       unpark<BOUNCE, TEX, QPRIMARY>(sh, MY_PARK());
     }

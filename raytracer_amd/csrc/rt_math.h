@@ -554,8 +554,8 @@ RT_HD void rt_node_slab_class2(const RtVec3& lo, const RtVec3& hi, const RtVec3&
 // rays, sinphi = |n| / (|e1||e2|)) that is R' = R + Q (|b| + 2R) / cosn with Q = 3 R c u (1/|e1| + 1/|e2|) / sinphi
 // stored per triangle (c = 64 there, for slack; the last term uses 2|e1||e2| / (|e1| + |e2|) <= 2R).
 // Rays nearly in the triangle's plane (small |det|) are where the reference's quotients are noise and may accept
-// anything: the test therefore never skips a triangle unless cosn > 2^-10, and slivers (sinphi < 1/64) and degenerate
-// triangles carry Q = +inf, which never passes.
+// anything: the test therefore never skips a triangle unless cosn > 2^-10 (for slivers, sinphi < 1/64: unless
+// cosn sinphi > 2^-16, through a shortened stored normal); degenerate triangles carry Q = +inf, which never passes.
 struct RtCullRec { float cx, cy, cz, R, nx, ny, nz, Q; };   // 32 B per leaf reference, in leaf order behind the triangle records
 struct RtBundle { float ox, oy, oz, ax, ay, az, r0, ksp, k1, bw; };   // k1 = 1 + ksp; bw >= |eye - o| for every ray
 #define RT_CULL_GUARD 0x1p-10f
@@ -583,11 +583,12 @@ inline RtCullRec rt_cull_record(const float* v0, const float* e1, const float* e
   r.nx = r.ny = r.nz = 0.f; r.Q = inf;
   if (nl > 0 && l1 > 0 && l2 > 0 && std::isfinite(nl) && std::isfinite(R)) {
     const double sinphi = nl / (l1 * l2);
-    r.nx = (float)(n[0] / nl); r.ny = (float)(n[1] / nl); r.nz = (float)(n[2] / nl);
-    if (sinphi >= 1.0 / 64) {
-      const double Q = 3.0 * R * 64.0 * 0x1p-24 * (1.0 / l1 + 1.0 / l2) / sinphi * 1.01;
-      if (std::isfinite(Q)) r.Q = (float)(Q * 1.001);
-    }
+    // (a sliver's normal is stored shortened, by 64 sinphi: the test's cosn then is a lower bound of 64 sinphi |d.n| / |n|, so that
+    //  passing its guard still means |det| >= 2^-16 |e1||e2|, far above what rounding can do to det)
+    const double shorten = sinphi < 1.0 / 64 ? 64 * sinphi : 1.0;
+    r.nx = (float)(n[0] / nl * shorten); r.ny = (float)(n[1] / nl * shorten); r.nz = (float)(n[2] / nl * shorten);
+    const double Q = 3.0 * R * 64.0 * 0x1p-24 * (1.0 / l1 + 1.0 / l2) / sinphi * 1.01;
+    if (std::isfinite(Q) && sinphi > 0x1p-40) r.Q = (float)(Q * 1.001);
   }
   return r;
 }

@@ -351,7 +351,7 @@ def triangle(q, other, tag, cur, nxt, masked):
          "s_mov_b32 %s, %s" % (RPRIM, s(q + 3)),
          "s_mov_b32 %s, %s" % (TCUR, nxt),                                                       # where the leaf goes on afterwards
          "@SAVE",
-         "s_mov_b32 %s, 2" % RES,
+         "@RES",
          "s_branch LT_out_%=",
          "LT_end%s_%%=:" % tag]
     out = []
@@ -359,6 +359,8 @@ def triangle(q, other, tag, cur, nxt, masked):
         if line == "@NEXT":
             out += (["s_ff1_i32_b64 %s, %s" % (JT, SURV), "s_bitset0_b64 %s, %s" % (SURV, JT), "s_add_u32 %s, %s, %s" % (JT, JT, RFIRST),
                      "s_lshl_b32 %s, %s, 6" % (nxt, JT)] if masked else ["s_add_u32 %s, %s, 0x40" % (nxt, cur)])
+        elif line == "@RES":
+            out.append("s_mov_b32 %s, %d" % (RES, 2 if masked else 3))     # (which of the two leaf loops to come back to)
         elif line == "@SAVE":
             out += ["v_writelane_b32 %s, s98, 62" % ST_FIRST, "v_writelane_b32 %s, s99, 63" % ST_FIRST] if masked else []
         else:
@@ -369,7 +371,7 @@ def triangle(q, other, tag, cur, nxt, masked):
 def cull():
     """Lane k of the wave (all 64 lanes, whatever the walk's lane sets say) and triangle k of the leaf: rt_cull_test of rt_math.h.
     Leaves the triangles worth testing in SURV, or goes on to the next child when there is none."""
-    P = ["s%d" % (36 + i) for i in range(10)]      # ox oy oz ax ay az r0 ksp k1 bw (the triangle registers are free here)
+    P = ["%%[b%d]" % i for i in range(10)]         # ox oy oz ax ay az r0 ksp k1 bw: scalar operands of the statement (wherever the compiler keeps them)
     ox, oy, oz, ax, ay, az, r0, ksp, k1, bw = P
     L = ["s_waitcnt lgkmcnt(0)",                                      # (a request of the leaf before may still be on its way into those registers)
          "s_mov_b64 %s, exec" % SURV,
@@ -381,7 +383,6 @@ def cull():
          "v_add_u32 v72, %s, v72" % CULL,
          "global_load_dwordx4 v[64:67], v72, s[%s:%s]" % (TRI[0][1:], TRI[1][1:]),
          "global_load_dwordx4 v[68:71], v72, s[%s:%s] offset:16" % (TRI[0][1:], TRI[1][1:])]
-    L += ["v_readlane_b32 %s, %s, %d" % (P[i], ST_FIRST, 32 + i) for i in range(10)]
     L += ["s_mov_b32 s46, 0xb6000000",                                # RT_CULL_P2_SLACK
           "s_waitcnt vmcnt(0)",
           "v_subrev_f32 v64, %s, v64" % ox,
@@ -421,14 +422,22 @@ def cull():
     return L
 
 
-def leaf():
+def leaf(with_cull):
     L = ["LT_leaf_%=:",
          "s_and_b32 %s, %s, 0xff" % (TEND, RMETA),
-         "s_cbranch_scc0 LT_next_%=",
-         "s_cmp_eq_u32 %s, 0" % CULL,
+         "s_cbranch_scc0 LT_next_%="]
+    if with_cull:
+        L += leaf_masked()
+    L += leaf_all()
+    return L
+
+
+def leaf_masked():
+    """A leaf entered with a bundle: the triangles that survive it, lowest bit first."""
+    L = ["s_cmp_eq_u32 %s, 0" % CULL,
          "s_cbranch_scc1 LT_leaf_all_%=",
-         "@MINTRIS"]
-    # ---- with a bundle: the triangles that survive it, lowest bit first
+         "s_bitcmp1_b32 %s, 8" % RMETA,                              # RT_LEAF_ASK: the host found the leaf's triangles worth asking about
+         "s_cbranch_scc0 LT_leaf_all_%="]
     L += cull()
     L += ["s_bitset1_b64 %s, 63" % SURV,
           "s_mov_b64 %s, 0" % CHG,
@@ -446,9 +455,13 @@ def leaf():
     L += triangle(TB, TA, "B", TNXT, TCUR, True)
     L += ["s_cmp_eq_u64 %s, 0" % SURV,
           "s_cbranch_scc0 LT_triA_%=",
-          "s_branch LT_leaf_done_%=",
-          # ---- without: every triangle of the leaf, one record after the other
-          "LT_leaf_all_%=:",
+          "s_branch LT_leaf_done_%="]
+    return L
+
+
+def leaf_all():
+    """Without a bundle: every triangle of the leaf, one record after the other."""
+    L = ["LT_leaf_all_%=:",
           "s_lshl_b32 %s, %s, 6" % (TCUR, RFIRST),
           "s_lshl_b32 %s, %s, 6" % (TEND, TEND),
           "s_add_u32 %s, %s, %s" % (TEND, TEND, TCUR),
@@ -478,32 +491,37 @@ def leaf():
     return L
 
 
-def block(pattern):
+def block(pattern, with_cull):
     L = ["s_waitcnt lgkmcnt(0)",
          "s_cmp_eq_u32 %s, 1" % RES,
-         "s_cbranch_scc1 LT_resume_exact_%=",
-         "s_cmp_eq_u32 %s, 2" % RES,
-         "s_cbranch_scc1 LT_resume_finish_%="]
+         "s_cbranch_scc1 LT_resume_exact_%="]
+    if with_cull:
+        L += ["s_cmp_eq_u32 %s, 2" % RES,
+              "s_cbranch_scc1 LT_resume_finish_%="]
+    L += ["s_cmp_eq_u32 %s, 3" % RES,
+          "s_cbranch_scc1 LT_resume_finish_all_%="]
     L += scan_sorted() if pattern == 0 else scan_zero(pattern)
-    L += leaf()
+    L += leaf(with_cull)
     L += [# ---- re-entries: the record of the next sibling is requested again (its registers were not kept outside)
           "LT_resume_exact_%=:",
           "s_lshl_b32 %s, %s, 5" % (OFF, IDX),
           "s_load_dwordx8 s[84:91], %s, %s" % (BLK, OFF),
-          "s_branch LT_after_exact_%=",
-          "LT_resume_finish_%=:",
+          "s_branch LT_after_exact_%="]
+    if with_cull:
+        L += ["LT_resume_finish_%=:",
+              "s_lshl_b32 %s, %s, 5" % (OFF, IDX),
+              "s_load_dwordx8 s[84:91], %s, %s" % (BLK, OFF),
+              "s_or_b64 %s, %s, %s" % (CHG, CHG, PASS),
+              "v_readlane_b32 s98, %s, 62" % ST_FIRST,
+              "v_readlane_b32 s99, %s, 63" % ST_FIRST,
+              "s_nop 0",
+              "s_cmp_eq_u64 %s, 0" % SURV,
+              "s_cbranch_scc1 LT_leaf_done_%=",
+              "s_branch LT_leaf_load_%="]
+    L += ["LT_resume_finish_all_%=:",
           "s_lshl_b32 %s, %s, 5" % (OFF, IDX),
           "s_load_dwordx8 s[84:91], %s, %s" % (BLK, OFF),
           "s_or_b64 %s, %s, %s" % (CHG, CHG, PASS),
-          "s_cmp_eq_u32 %s, 0" % CULL,
-          "s_cbranch_scc1 LT_resume_all_%=",
-          "v_readlane_b32 s98, %s, 62" % ST_FIRST,
-          "v_readlane_b32 s99, %s, 63" % ST_FIRST,
-          "s_nop 0",
-          "s_cmp_eq_u64 %s, 0" % SURV,
-          "s_cbranch_scc1 LT_leaf_done_%=",
-          "s_branch LT_leaf_load_%=",
-          "LT_resume_all_%=:",
           "s_cmp_lt_u32 %s, %s" % (TCUR, TEND),
           "s_cbranch_scc0 LT_leaf_done_%=",
           "s_branch LT_leaf_load_all_%=",
@@ -517,21 +535,33 @@ def block(pattern):
     return L
 
 
+def statement(with_cull):
+    # ONE assembly statement with the seven copies behind a dispatch on the pattern (s18): several statements in a
+    # switch would have the compiler merge their scalar outputs through values it no longer knows to be wave-uniform
+    L = []
+    for pattern in range(1, 7):
+        L += ["s_cmp_eq_u32 s18, %d" % pattern, "s_cbranch_scc1 LT%d_begin_%%=" % pattern]
+    for pattern in range(7):
+        B = ["LT%d_begin_%%=:" % pattern] + block(pattern, with_cull) + ["s_branch LT_end_all_%="]
+        L += [line.replace("LT_", "LT%d_" % pattern) if "LT_end_all" not in line else line for line in B]
+        print("cull" if with_cull else "plain", "pattern", pattern, len(B), "lines")
+    L += ["LT_end_all_%=:"]
+    return L
+
+
+def emit(line):
+    if line == "@PRIO":
+        return 'RT_PRIO_STEP'
+    return '"%s\\n"' % line
+
+
 def main():
     out = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "raytracer_amd", "csrc", "rt_trace_asm.inc")
     with open(out, "w") as f:
-        f.write("// Generated by tools/gen_trace_asm.py - do not edit.  Register map and operands: rt_kernel_wave.hip (trace_wave).\n")
-        f.write("// RT_TRACE_ASM_0: rays that agree on their direction signs; RT_TRACE_ASM_1 .. _6: rays that share a zero pattern (bit k: component k is zero).\n")
-        # ONE assembly statement with the seven copies behind a dispatch on the pattern (s18): several statements in a
-        # switch would have the compiler merge their scalar outputs through values it no longer knows to be wave-uniform
-        L = []
-        for pattern in range(1, 7):
-            L += ["s_cmp_eq_u32 s18, %d" % pattern, "s_cbranch_scc1 LT%d_begin_%%=" % pattern]
-        for pattern in range(7):
-            B = ["LT%d_begin_%%=:" % pattern] + block(pattern) + ["s_branch LT_end_all_%="]
-            L += [("LT%d_@MINTRIS" % pattern if line == "@MINTRIS" else line.replace("LT_", "LT%d_" % pattern)) if "LT_end_all" not in line else line for line in B]
-            print("pattern", pattern, len(B), "lines")
-        L += ["LT_end_all_%=:"]
+        f.write("// Generated by tools/gen_trace_asm.py - do not edit.  Register map and operands: rt_kernel_wave.hip (walk_asm, trace_wave).\n")
+        f.write("// RT_TRACE_ASM_CULL: the walk with the bundle test in front of a leaf's triangles (operands %[b0] .. %[b9], s19);\n")
+        f.write("// RT_TRACE_ASM_PLAIN: the walk that tests every triangle of every leaf it enters (kernels whose rays never form a bundle).\n")
+        f.write("// In both, one copy per kind of node test: rays that agree on their direction signs (s18 = 0), rays that share a zero pattern (s18 = 1 .. 6, bit k: component k is zero).\n")
         # Measurement builds (-DRT_WALK_PRIO=k): a wave counts the leaves it enters (s23, zeroed by the caller) and raises its issue
         # priority after 2^k, 2^(k+1) and 2^(k+2) of them (a branch over one instruction is written as its offset, not a label).
         f.write("#ifdef RT_WALK_PRIO\n#define RT_PRIO_STR2(x) #x\n#define RT_PRIO_STR(x) RT_PRIO_STR2(x)\n"
@@ -540,19 +570,10 @@ def main():
                 "  \"s_bitcmp1_b32 s23, \" RT_PRIO_STR(RT_WALK_PRIO) \"+1\\n\" \"s_cbranch_scc0 1\\n\" \"s_setprio 2\\n\" \\\n"
                 "  \"s_bitcmp1_b32 s23, \" RT_PRIO_STR(RT_WALK_PRIO) \"+2\\n\" \"s_cbranch_scc0 1\\n\" \"s_setprio 3\\n\"\n"
                 "#else\n#define RT_PRIO_STEP \"\"\n#endif\n")
-        # A leaf with fewer than RT_CULL_MIN_TRIS triangles is walked from end to end even when there is a bundle (asking costs about
-        # as much as two and a half triangle tests).
-        f.write("#ifndef RT_CULL_MIN_TRIS\n#define RT_CULL_MIN_TRIS 3\n#endif\n#define RT_MINTRIS_STR2(x) #x\n#define RT_MINTRIS_STR(x) RT_MINTRIS_STR2(x)\n")
-        f.write("#define RT_TRACE_ASM \\\n")
-        def emit(line):
-            if line == "@PRIO":
-                return 'RT_PRIO_STEP'
-            if "@MINTRIS" in line:
-                pat = line.split("@MINTRIS")[0]
-                return '"s_cmp_lt_u32 %s, " RT_MINTRIS_STR(RT_CULL_MIN_TRIS) "\\n" "s_cbranch_scc1 %sleaf_all_%%=\\n"' % (TEND, pat)
-            return '"%s\\n"' % line
-        f.write(" \\\n".join(emit(line) for line in L))
-        f.write("\n")
+        for name, with_cull in (("RT_TRACE_ASM_CULL", True), ("RT_TRACE_ASM_PLAIN", False)):
+            f.write("#define %s \\\n" % name)
+            f.write(" \\\n".join(emit(line) for line in statement(with_cull)))
+            f.write("\n")
     print("wrote", os.path.normpath(out))
 
 
