@@ -84,7 +84,11 @@ enum {
   /* Deal the tiles of the launch to the chip's dies in strips whatever their number (the library does so by itself from
    * 4 000 tiles on).  For callers that keep several frames or bands in flight on different streams: together those fill
    * the chip, and each die's L2 then keeps meeting its own part of the scene.  A single small launch is slower this way. */
-  RT_RENDER_STRIPS = 32
+  RT_RENDER_STRIPS = 32,
+  /* Test every triangle of every leaf a ray enters, as octtree.cu:264-274 does.  Without this flag a wave first rules out
+   * the triangles of a leaf that none of its rays can be accepted by (same bytes: a test that rejects changes nothing);
+   * the flag is there for cross-checks and measurements. */
+  RT_RENDER_EVERY_TRIANGLE = 64
 };
 
 /* Parse resources + scene, load and transform meshes, build the octree.

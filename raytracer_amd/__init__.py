@@ -25,6 +25,7 @@ RT_RENDER_LITERAL = 4
 RT_RENDER_STACKED = 8
 RT_RENDER_QUEUED = 16
 RT_RENDER_STRIPS = 32
+RT_RENDER_EVERY_TRIANGLE = 64
 
 # Every symbol include/rt_amd.h declares.
 ABI_SYMBOLS = (

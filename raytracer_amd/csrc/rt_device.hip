@@ -187,7 +187,7 @@ struct rt_dscene {
   RenderCtx ctx;
 };
 
-extern "C" const char* rt_version(void) { return "rt_amd 2.2 gfx950 (wave-synchronous traversal in gfx950 assembly, exact division-free predicates)"; }
+extern "C" const char* rt_version(void) { return "rt_amd 2.3 gfx950 (wave-synchronous traversal in gfx950 assembly, exact division-free predicates, leaf triangles ruled out per wave)"; }
 
 extern "C" void rt_dscene_destroy(rt_dscene* d) {
   if (!d) return;
@@ -396,6 +396,7 @@ int render_wavefront(const SceneArrays& S, RenderCtx& ctx, const RowMap& rows, b
 int launch_render(const SceneArrays& S, RenderCtx& ctx, RowMap rows, uint8_t* d_rgb, int32_t* d_ids, float* d_t, hipStream_t stream,
                   unsigned flags, rt_stats* stats) {
   rows.strips = (flags & RT_RENDER_STRIPS) ? 1 : 0;
+  rows.every_triangle = (flags & RT_RENDER_EVERY_TRIANGLE) ? 1 : 0;
   const bool bounce = S.info.has_bounce_materials != 0, count = (flags & RT_RENDER_COUNT_TESTS) != 0;
   // Queues pay where rays scatter inside a glass mesh (glass bunny 1920x1080: 8.2 -> 4.3 ms, 512x512: 4.9 -> 3.7 ms; a tie
   // at 4K); mirrors and sphere scenes are faster on the lanes' stacks (their bounce rays stay neighbours, and the term

@@ -1580,8 +1580,7 @@ void rt_launch_wave_kernel(const RtDeviceView& V, const RowMap& rows, bool bounc
   // (small meshes: what a wave saves in their few leaves does not pay for working out its bundle - boxedSpheres, 12 triangles: + 16 %;
   //  rays from the queues: scattered by construction, their bundles rule nothing out)
   static const int cull_min_nodes = getenv("RT_AMD_CULL_MIN_NODES") ? atoi(getenv("RT_AMD_CULL_MIN_NODES")) : 512;
-  static const bool cull_queued = getenv("RT_AMD_CULL_QUEUED") != nullptr;
-  A.cull_offset = (no_cull || V.n_wnodes < cull_min_nodes || (wf.in && !cull_queued)) ? 0u : V.cull_offset; A.pad_ = 0u;
+  A.cull_offset = (no_cull || rows.every_triangle || V.n_wnodes < cull_min_nodes || wf.in != nullptr) ? 0u : V.cull_offset; A.pad_ = 0u;
   static const float cull_r0 = getenv("RT_AMD_CULL_R0") ? (float)atof(getenv("RT_AMD_CULL_R0")) : 1.0f;      // measurements
   static const float cull_ksp = getenv("RT_AMD_CULL_KSP") ? (float)atof(getenv("RT_AMD_CULL_KSP")) : 0.25f;
   A.cull_r0_max = cull_r0; A.cull_ksp_max = cull_ksp;

@@ -40,7 +40,7 @@ struct RtDeviceView {
 // when `compact` is 0 and at row lr of a band-packed buffer when it is 1.
 // small != 0: a wave owns a 4x4 tile (16 of its 64 lanes carry a pixel) and a workgroup 8x8 pixels; used for frames with
 // too few 8x8 tiles to fill the chip, where four times as many, shorter walks finish sooner.
-struct RowMap { int32_t row0, band_rows, band_stride, n_local, compact, small, strips; };   // strips (host side): 1 = deal the tiles to the dies in strips whatever their number
+struct RowMap { int32_t row0, band_rows, band_stride, n_local, compact, small, strips, every_triangle; };   // host side: strips = 1: deal the tiles to the dies in strips whatever their number; every_triangle = 1: no bundle test in front of a leaf's triangles
 
 enum { C_RAYS = 0, C_SHADOW, C_NODE, C_LEAF, C_TRI, C_SPH, C_UB_LEAVE, C_UB_OVER, C_UB_STACK, C_TRACED,
        // wave-level iteration counts of the instrumented production kernel (how often each code path runs)

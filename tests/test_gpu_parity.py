@@ -506,3 +506,19 @@ def test_queue_overflow_falls_back_to_the_stacks(monkeypatch):
     for k in ("rays", "shadow_rays", "rays_traced"):
         assert sg[k] == sw[k] == sa[k], (k, sg[k], sw[k], sa[k])
 
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", ["meshDragon", "meshMedBunny", "meshTorus", "meshReflectedSquircle", "meshTransparentBunny"])
+@pytest.mark.parametrize("w,h", [(333, 187), (1280, 720)])
+def test_skipping_triangles_changes_nothing(name, w, h):
+    # the wave-level triangle skip against RT_RENDER_EVERY_TRIANGLE (octtree.cu:264-274 as written): same bytes, same
+    # hit ids and distances, same ray counts - on 4x4 and 8x8 tiles, ragged edges, bounce rays on the stacks and from queues
+    ds = rt.DeviceScene(rt.Scene("scenes/%s.json" % name, w, h, 3))
+    ways = [0, rt.RT_RENDER_STACKED] if name == "meshTransparentBunny" else [0]
+    for way in ways:
+        a, ida, ta, sa = ds.render_host(flags=way)
+        b, idb, tb, sb = ds.render_host(flags=way | rt.RT_RENDER_EVERY_TRIANGLE)
+        assert np.array_equal(a, b) and np.array_equal(ida, idb) and np.array_equal(ta.view(np.uint32), tb.view(np.uint32))
+        for k in ("rays", "shadow_rays", "rays_traced"):
+            assert sa[k] == sb[k], (k, sa[k], sb[k])
