@@ -781,6 +781,8 @@ void load_scene_into(rt_scene& sc, const std::string& scene_path, const std::str
     sc.cull_offset = (uint32_t)(n_rec * sizeof(RtTriLeaf));
     RtCullRec* const cull = reinterpret_cast<RtCullRec*>(sc.tri_leaf.data() + n_rec);
     for (size_t r = sc.leaf_refs.size(); r < n_rec; r++) cull[r] = RtCullRec{0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, __builtin_inff()};
+    std::vector<RtCullRec> cull_of(sc.tri_geom.size());   // (a triangle sits in several leaves: its record is worked out once)
+    for (size_t t = 0; t < sc.tri_geom.size(); t++) cull_of[t] = rt_cull_record(sc.tri_geom[t].v0, sc.tri_geom[t].e1, sc.tri_geom[t].e2);
     for (size_t r = 0; r < sc.leaf_refs.size(); r++) {
       const RtTriGeom& g = sc.tri_geom[sc.leaf_refs[r]];
       RtTriLeaf& t = sc.tri_leaf[r];
@@ -791,7 +793,7 @@ void load_scene_into(rt_scene& sc, const std::string& scene_path, const std::str
       t.nx = g.e1[1] * g.e2[2] - g.e1[2] * g.e2[1];
       t.ny = -g.e1[0] * g.e2[2] + g.e1[2] * g.e2[0];
       t.nz = g.e1[0] * g.e2[1] - g.e1[1] * g.e2[0];
-      cull[r] = rt_cull_record(g.v0, g.e1, g.e2);
+      cull[r] = cull_of[sc.leaf_refs[r]];
     }
     // The walk visits children in the fixed order 0..7 whatever the ray, so "what comes after this subtree" is a property of
     // the node: its next sibling that is not an empty leaf, else what comes after its parent.  With that link per node a

@@ -57,6 +57,15 @@ __device__ __forceinline__ uint32_t uni(uint32_t v) { return __builtin_amdgcn_re
 #define RT_PATHS_ON false
 #endif
 
+// Measurement builds (-DRT_WALK_PRIO=k): the wave's count of leaves entered travels from render_wave down to the assembly walk.
+#ifdef RT_WALK_PRIO
+#define RT_WORK_PARAM , uint32_t& rt_walk_work
+#define RT_WORK_ARG , rt_walk_work
+#else
+#define RT_WORK_PARAM
+#define RT_WORK_ARG
+#endif
+
 // Minimum of a value over the 64 lanes, the same in every lane (all lanes active): quad swaps and row mirrors, then the
 // four rows through scalar registers.
 __device__ __forceinline__ float wave_min(float v) {
@@ -136,7 +145,7 @@ __device__ __forceinline__ bool wave_bundle(uint64_t cls, const RtVec3& e, const
 template <bool CULL>
 __device__ __forceinline__ uint64_t walk_asm(const float4* nodes, uint32_t variant, uint32_t zpat, const float4* tri_leaf, uint32_t top_first, uint32_t rem,
                                              uint64_t live, const RtVec3& e, const RtVec3& d, const RtVec3& inv, const RtVec3& fc, float neg_eb,
-                                             float stop_t, Hit& hit, WaveStack& st, float* bary_lds, uint32_t cull, const RtBundle& bundle) {
+                                             float stop_t, Hit& hit, WaveStack& st, float* bary_lds, uint32_t cull, const RtBundle& bundle RT_WORK_PARAM) {
   const RtVec3 c2 = {-d.x, -d.y, -d.z};
   // (wave-uniform values, pinned to scalar registers once: the walk reads them on every leaf it enters)
   const uint32_t b0 = uni(__float_as_uint(bundle.ox)), b1 = uni(__float_as_uint(bundle.oy)), b2 = uni(__float_as_uint(bundle.oz)), b3 = uni(__float_as_uint(bundle.ax)),
@@ -150,7 +159,7 @@ __device__ __forceinline__ uint64_t walk_asm(const float4* nodes, uint32_t varia
   const float cmax = rt_max3(fabsf(fc.x), fabsf(fc.y), fabsf(fc.z));
   float a_det = 0.f, a_nb = 0.f, a_ng = 0.f, a_nt = 0.f;
 #ifdef RT_WALK_PRIO
-  uint32_t a_work = 0u;   // measurement builds: leaves entered by this walk (see RT_PRIO_STEP in rt_trace_asm.inc)
+  uint32_t a_work = uni(rt_walk_work);   // measurement builds: leaves entered by the wave so far, over all its walks (see RT_PRIO_STEP in rt_trace_asm.inc)
 #define RT_PRIO_OPERAND , "+{s23}"(a_work)
 #else
 #define RT_PRIO_OPERAND
@@ -224,6 +233,9 @@ __device__ __forceinline__ uint64_t walk_asm(const float4* nodes, uint32_t varia
       }
     }
   }
+#ifdef RT_WALK_PRIO
+  rt_walk_work = a_work;
+#endif
   return a_live;
 }
 
@@ -235,7 +247,7 @@ template <bool COUNT, bool CULLABLE>
 __device__ __forceinline__ void trace_wave(const float4* __restrict__ nodes, int n_wnodes, const float4* __restrict__ tri_leaf,
                                            const RtSphere* __restrict__ spheres, int n_spheres, bool has_oct, bool want,
                                            const RtVec3& e, const RtVec3& d, float stop_t, Hit& hit, WaveStack& st,
-                                           int lane, Tally& tl, float* cull_lds, uint32_t cull_offset, float cull_r0_max, float cull_ksp_max) {
+                                           int lane, Tally& tl, float* cull_lds, uint32_t cull_offset, float cull_r0_max, float cull_ksp_max RT_WORK_PARAM) {
   // Lane sets are kept as wave-uniform 64-bit masks in SGPRs (who still has an undecided ray, who entered the
   // current branch, who accepted the current node, ...); they are combined on the scalar unit and only turned
   // back into a per-lane predicate on the rare paths that need one.
@@ -362,7 +374,7 @@ __device__ __forceinline__ void trace_wave(const float4* __restrict__ nodes, int
     if ((presorted || zpat != 0u) && FUSED && (rem & 0xffu) != 0u) {
       RtBundle bundle = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
       const uint32_t cull = (CULLABLE && cull_offset != 0u && wave_bundle(live, e, d, stop_t, bundle, cull_r0_max, cull_ksp_max)) ? cull_offset : 0u;
-      live = walk_asm<CULLABLE>(nodes, variant, zpat, tri_leaf, top_first, rem, live, e, d, inv, fc, neg_eb, stop_t, hit, st, nullptr, cull, bundle);
+      live = walk_asm<CULLABLE>(nodes, variant, zpat, tri_leaf, top_first, rem, live, e, d, inv, fc, neg_eb, stop_t, hit, st, nullptr, cull, bundle RT_WORK_ARG);
       if (!live) return;
     } else {
 #endif
@@ -825,7 +837,7 @@ __device__ __forceinline__ void trace_wave(const float4* __restrict__ nodes, int
 __device__ __forceinline__ uint64_t trace_class(const float4* __restrict__ nodes, int n_wnodes, const float4* __restrict__ tri_leaf,
                                                 const RtSphere* __restrict__ spheres, int n_spheres, bool has_oct, bool want,
                                                 const RtVec3& e, const RtVec3& d, float stop_t, Hit& hit, WaveStack& st, float* bary_lds,
-                                                uint32_t cull_offset, float cull_r0_max, float cull_ksp_max) {
+                                                uint32_t cull_offset, float cull_r0_max, float cull_ksp_max RT_WORK_PARAM) {
   const uint64_t pending = __builtin_amdgcn_ballot_w64(want);
   if (!pending) return 0ull;
   uint64_t cls = pending, after = pending;
@@ -856,7 +868,7 @@ __device__ __forceinline__ uint64_t trace_class(const float4* __restrict__ nodes
       }
       RtBundle bundle = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
       const uint32_t cull = (cull_offset != 0u && wave_bundle(cls, e, d, stop_t, bundle, cull_r0_max, cull_ksp_max)) ? cull_offset : 0u;
-      after = walk_asm<true>(vnodes, variant, zpat, tri_leaf, top_first, rem, cls, e, d, inv, fu.c, neg_eb, stop_t, hit, st, bary_lds, cull, bundle);
+      after = walk_asm<true>(vnodes, variant, zpat, tri_leaf, top_first, rem, cls, e, d, inv, fu.c, neg_eb, stop_t, hit, st, bary_lds, cull, bundle RT_WORK_ARG);
     }
   }
   if (n_spheres > 0 && after) {
@@ -1093,6 +1105,9 @@ __global__ __launch_bounds__(RT_WBLOCK, (BOUNCE && !QPRIMARY) ? RT_WAVES_PER_SIM
   auto count = [&](int which) { __hip_atomic_fetch_add(MY_COUNTS() + which * RT_WBLOCK, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); };
   __shared__ float cull_sh[16 * (RT_WBLOCK / 64)];   // bounds of the wave's rays during a walk (trace_wave)
   WaveStack st = {0u, 0u, 0u, 0u};
+#ifdef RT_WALK_PRIO
+  uint32_t rt_walk_work = 0u;
+#endif
   // Pixel of a thread: wave w of the block owns the 8x8 tile (w % RT_WAVES_X, w / RT_WAVES_X) of the block's pixels.  The
   // coordinates are needed at the start, after the primary ray and at the end; they are derived again each time
   // from an opaque copy of the thread index, so that none of them occupies a register (or a spill slot) in between.
@@ -1274,11 +1289,11 @@ __global__ __launch_bounds__(RT_WBLOCK, (BOUNCE && !QPRIMARY) ? RT_WAVES_PER_SIM
       if (LANES) trace_lanes(nodes, LATE(node_skip), tri_leaf, spheres, n_spheres, has_oct != 0, want, tr_e, tr_d, stop_t, h);
       else if (CLASSES) {
         float* const bary = parked + (SW + 4) * RT_WBLOCK + (RT_WBLOCK == 64 ? 0 : (TID() & ~63));   // the wave's columns of the two barycentric words
-        traced = in_mask(trace_class(nodes, n_wnodes, tri_leaf, spheres, n_spheres, has_oct != 0, want, tr_e, tr_d, stop_t, h, st, bary, LATE(cull_offset), LATE(cull_r0_max), LATE(cull_ksp_max)));
+        traced = in_mask(trace_class(nodes, n_wnodes, tri_leaf, spheres, n_spheres, has_oct != 0, want, tr_e, tr_d, stop_t, h, st, bary, LATE(cull_offset), LATE(cull_r0_max), LATE(cull_ksp_max) RT_WORK_ARG));
         asm volatile("" ::: "memory");
         h.bet = bary[LANE()]; h.gam = bary[RT_WBLOCK + LANE()];   // (only meaningful, and only used, when a triangle was hit)
       }
-      else trace_wave<COUNT, !queued && !COUNT>(nodes, n_wnodes, tri_leaf, spheres, n_spheres, has_oct != 0, want, tr_e, tr_d, stop_t, h, st, LANE(), tl, cull_sh + 16 * (TID() >> 6), COUNT ? 0u : LATE(cull_offset), LATE(cull_r0_max), LATE(cull_ksp_max));
+      else trace_wave<COUNT, !queued && !COUNT>(nodes, n_wnodes, tri_leaf, spheres, n_spheres, has_oct != 0, want, tr_e, tr_d, stop_t, h, st, LANE(), tl, cull_sh + 16 * (TID() >> 6), COUNT ? 0u : LATE(cull_offset), LATE(cull_r0_max), LATE(cull_ksp_max) RT_WORK_ARG);
       asm volatile("" ::: "memory");
       unpark<BOUNCE, TEX, QPRIMARY>(sh, MY_PARK());
     }

@@ -8,7 +8,8 @@
 //   host_cull_check random <count> <seed>
 //       adversarial pairs: single rays and narrow bundles that miss a random triangle (slivers, specks, large ones) by
 //       10^-7 .. 10^-1, rays in the triangle's plane and parallel to its edges, origins inside the plane.
-// Prints "checked <pairs> skipped <n> (<pct>%) mismatches <m>" and exits non-zero when m > 0.
+// Prints "checked <pairs> skipped <n> (<pct>%) accepted <a> mismatches <m>" (scene mode: also the leaf visits left without a
+// triangle) and exits non-zero when m > 0.
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -19,7 +20,7 @@
 #include "../include/rt_amd.h"
 #include "../raytracer_amd/csrc/rt_math.h"
 
-static uint64_t n_pairs = 0, n_skip = 0, n_bad = 0, n_accept = 0;
+static uint64_t n_pairs = 0, n_skip = 0, n_bad = 0, n_accept = 0, n_leaves = 0, n_leaves_emptied = 0;
 
 struct Ray { RtVec3 e, d; };
 
@@ -72,16 +73,18 @@ static void walk(const Tree& T, int node, const std::vector<Ray>& rays, std::vec
       if (mask[i] && rt_node_accept_literal({b[0], b[1], b[2]}, {b[3], b[4], b[5]}, rays[i].e, rays[i].d, hits[i].t)) { m[i] = 1; cnt++; }
     if (!cnt) continue;
     if (T.kind[ch] < 0) { walk(T, ch, rays, hits, m, B); continue; }
+    int left = 0;
     for (int k = 0; k < T.kind[ch]; k++) {
       const int id = T.refs[T.ref_first[ch] + k];
       const float* v = &T.verts[9 * id];
       const float e1[3] = {v[3] - v[0], v[4] - v[1], v[5] - v[2]}, e2[3] = {v[6] - v[0], v[7] - v[1], v[8] - v[2]};
-      check(v, e1, e2, rays, B);
+      if (!check(v, e1, e2, rays, B)) left++;
       for (size_t i = 0; i < rays.size(); i++) if (m[i]) {
         float t, bb, gg;
         if (rt_triangle_test({v[0], v[1], v[2]}, {e1[0], e1[1], e1[2]}, {e2[0], e2[1], e2[2]}, rays[i].e, rays[i].d, hits[i].t, t, bb, gg)) hits[i] = {t, id, bb, gg};
       }
     }
+    n_leaves++; if (!left) n_leaves_emptied++;
   }
 }
 
@@ -189,6 +192,7 @@ int main(int ac, char** av) {
   if (ac > 1 && !strcmp(av[1], "scene")) rc = run_scene(ac, av);
   else if (ac > 1 && !strcmp(av[1], "random")) rc = run_random(ac, av);
   if (rc) return rc;
+  if (n_leaves) printf("leaf visits %llu, without a triangle left %llu (%.1f%%)\n", (unsigned long long)n_leaves, (unsigned long long)n_leaves_emptied, 100.0 * n_leaves_emptied / n_leaves);
   printf("checked %llu skipped %llu (%.1f%%) accepted %llu mismatches %llu \n", (unsigned long long)n_pairs, (unsigned long long)n_skip,
          n_pairs ? 100.0 * n_skip / n_pairs : 0.0, (unsigned long long)n_accept, (unsigned long long)n_bad);
   return n_bad ? 1 : 0;

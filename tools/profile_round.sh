@@ -20,5 +20,8 @@ bash tools/profile_scene.sh "${tag}_c5" meshTransparentBunny 3840x2160 3 > "$out
 f=$(find "gpurun_out/prof_${tag}_c5/trace" -name '*kernel_trace.csv' | head -1)
 python3 tools/frame_timeline.py "$f" > "$out/c5_frame_timeline.txt"
 cp "gpurun_out/prof_${tag}_c5/kernel_stats.csv" "$out/c5_kernel_stats.csv"
-(cd assets && timeout -k 10 120 ../raytracer_amd/run -s scenes/meshDragon.json -w 3840 -h 2160 -i /tmp/dragon_4k.png --stats > "$out/cli_stats_dragon.json" 2> "$out/cli_stats_dragon.log")
+# (three processes, the last one's phases are kept: the first process on a box pays for the machine's first use of the GPU)
+for rep in 1 2 3; do
+  (cd assets && timeout -k 10 120 ../raytracer_amd/run -s scenes/meshDragon.json -w 3840 -h 2160 -i /tmp/dragon_4k.png --stats > "$out/cli_stats_dragon.json" 2> "$out/cli_stats_dragon.log")
+done
 tail -2 "$out/c5_frame_timeline.txt"; cat "$out/cli_stats_dragon.json"
