@@ -255,6 +255,9 @@ def main():
             prof = committed_counters(rt.kernel_source_sha256()) if headline else None
             roofline = {"bound": "valu_fp32", "achieved": ach, "peak": PEAK_FP32_TFLOPS, "unit": "TFLOP/s",
                         "frac": ach / PEAK_FP32_TFLOPS,
+                        # (the kernel proves most triangle tests of a leaf rejected for a whole wave without executing them, and stops
+                        #  shadow rays at their first hit: `achieved` prices the tests the reference makes, executed_* what ran)
+                        "frac_is": "FLOP of the node / triangle / sphere tests and shading the REFERENCE performs for this frame, over the kernel's time and the FP32 peak: work delivered, not work executed (see executed_tflops)",
                         # HBM bytes per launch (FETCH_SIZE + WRITE_SIZE of the counter passes committed for exactly these kernel sources; null otherwise)
                         "traffic": prof.get("traffic_bytes_per_launch") if prof else None,
                         "kernel": "render_wave", "kernel_ms": kernel_ms, "launches_overlap": bool(two_deep), "test_counts_from": counts_from, "flop_per_ray": flop / ref["rays"],
