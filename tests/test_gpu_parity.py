@@ -522,3 +522,39 @@ def test_skipping_triangles_changes_nothing(name, w, h):
         assert np.array_equal(a, b) and np.array_equal(ida, idb) and np.array_equal(ta.view(np.uint32), tb.view(np.uint32))
         for k in ("rays", "shadow_rays", "rays_traced"):
             assert sa[k] == sb[k], (k, sa[k], sb[k])
+
+
+_CULL_CHILD = """
+import hashlib, sys
+import numpy as np
+import raytracer_amd as rt
+from scenes_common import ALL_SCENES
+for name in ALL_SCENES:
+    for w, h in ((128, 128), (333, 187)):
+        ds = rt.DeviceScene(rt.Scene("scenes/%s.json" % name, w, h, 3))
+        rgb, ids, ts, st = ds.render_host()
+        print(name, w, h, hashlib.sha256(rgb.tobytes() + ids.tobytes() + ts.tobytes()).hexdigest(), st["rays"], st["rays_traced"])
+"""
+
+
+@pytest.mark.gpu
+def test_skipping_triangles_on_small_meshes_too():
+    # Meshes below 512 nodes are rendered without the triangle skip (it does not pay there); the limit is read once per
+    # process, so a child process with the limit at zero renders every scene with it - boxes and planes made of a few huge
+    # triangles, walls that shadow rays run along - and must produce the bytes, ids, distances and ray counts of this one.
+    import os
+    import subprocess
+    import sys
+    from scenes_common import HERE
+    want = []
+    for name in ALL_SCENES:
+        for w, h in ((128, 128), (333, 187)):
+            ds = rt.DeviceScene(rt.Scene("scenes/%s.json" % name, w, h, 3))
+            rgb, ids, ts, st = ds.render_host(flags=rt.RT_RENDER_EVERY_TRIANGLE)
+            want.append("%s %d %d %s %d %d" % (name, w, h, hashlib.sha256(rgb.tobytes() + ids.tobytes() + ts.tobytes()).hexdigest(),
+                                               st["rays"], st["rays_traced"]))
+    env = dict(os.environ, RT_AMD_CULL_MIN_NODES="0")
+    env["PYTHONPATH"] = os.pathsep.join([os.path.join(HERE, ".."), HERE, env.get("PYTHONPATH", "")])
+    out = subprocess.run([sys.executable, "-c", _CULL_CHILD], env=env, capture_output=True, text=True, timeout=110)
+    assert out.returncode == 0, out.stderr[-2000:]
+    assert out.stdout.strip().splitlines() == want
