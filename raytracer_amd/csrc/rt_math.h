@@ -536,11 +536,12 @@ RT_HD void rt_node_slab_class2(const RtVec3& lo, const RtVec3& hi, const RtVec3&
 // leaves such tests out when it can prove the rejection for all of its rays at once: on entering a leaf, lane k takes
 // triangle k and asks whether any ray of the wave's BUNDLE can come near it.
 //
-// The bundle (RtBundle) bounds the wave's ray lines: every point X of every line lies within r0 + ksp * s of the axis
-// (o, a), s being the distance of X from the point of its line nearest o (o is a point all the lines pass close to - the
-// eye, a point light - or just a point of one of them; a is their mean direction; r0 the largest distance of a line
-// from o, ksp the largest |d - a|).  A line that enters the ball (c, R') therefore does so at s <= |c - o| + R', i.e.
-// within r0 + ksp (|c - o| + R') of the axis, and cannot if the centre is further from the axis than that plus R'.
+// The bundle (RtBundle) bounds the wave's ray lines: every point X = q + s d of every line (q: the point of the line nearest
+// o) lies within r0 + k |s| of the axis (o, a) - o is a point all the lines pass close to (the eye, a point light) or
+// just a point of one of them, a a unit vector between their directions, r0 the largest distance of a line from o, k
+// the largest |d - a|.  A line that enters the ball (c, R') does so where |s||d| <= |c - o| + R', and |d| >= 1 - k, so
+// with ksp = k / (1 - k) it does so within r0 + ksp (|c - o| + R') of the axis, and cannot if the centre is further from
+// the axis than that plus R'.
 //
 // What R' has to be for "the line misses the ball" to imply "triangle.cu:107-152 rejects", in float arithmetic:
 // with b = eye - v0, n = e1 x e2 and det = -d.n, the reference accepts only if its rounded numerators satisfy
@@ -608,7 +609,10 @@ RT_HD RtBundle rt_bundle_finish(const RtVec3& o, const RtVec3& a, float r0, floa
   RtBundle B;
   B.ox = o.x; B.oy = o.y; B.oz = o.z; B.ax = a.x; B.ay = a.y; B.az = a.z;
   B.r0 = fmaf(r0, 1.001f, fmaf(bw, 0x1p-18f, 1e-6f));
-  B.ksp = fmaf(k, 1.001f, 0x1p-18f);
+  // (a direction need not be a unit vector: |d| >= 1 - k, so a line reaches the ball (c, R') within (|c - o| + R') / (1 - k) of
+  //  its point nearest o; that factor goes into the spread)
+  const float ks = fmaf(k, 1.001f, 0x1p-18f);
+  B.ksp = ks < 0.9f ? ks / (1.f - ks) * 1.000001f : __builtin_inff();
   B.k1 = (1.f + B.ksp) * 1.000001f;
   B.bw = fmaf(bw, 1.001f, 1e-4f);
   return B;
@@ -627,7 +631,11 @@ RT_HD bool rt_cull_test(const RtCullRec& t, const RtBundle& B) {
   const float reach = fmaf(B.ksp, vl, fmaf(t.R, B.k1, B.r0));          // r0 + R k1 + ksp |v|
   const float lhs = (p - reach) * cosn;
   const float rhs = t.Q * fmaf(4.f, t.R, B.bw + vl) * B.k1;            // margin (1 + ksp) cosn, with |b| <= bw + |v| + R
+#ifdef RT_CULL_TEST_WITHOUT_MARGIN   // (only ever defined by tests/test_host_cull.py: the harness has to notice when margin and guard are missing)
+  return p - reach > 0.f;
+#else
   return lhs > rhs && cosn > RT_CULL_GUARD;
+#endif
 }
 
 #endif

@@ -44,3 +44,17 @@ def test_tiles_of_real_frames(harness, scene, w, h, stride, least):
     pairs, skipped = _run([harness, "scene", rt.asset("scenes/%s.json" % scene), os.path.join(rt.ASSETS, "resources.json"), rt.ASSETS,
                            str(w), str(h), str(stride)])
     assert skipped >= least * pairs, (pairs, skipped)
+
+
+def test_the_harness_notices_a_skip_without_margin_and_guard(harness):
+    # the same harness built with the geometric part of the test alone (no rounding margin, no guard against rays in a
+    # triangle's plane) must find triangles that are skipped although the literal solve accepts them
+    exe = EXE + "_nomargin"
+    src = os.path.join(ROOT, "tests", "host_cull_check.cpp")
+    libdir = os.path.join(ROOT, "raytracer_amd")
+    subprocess.check_call(["g++", "-std=c++17", "-O2", "-ffp-contract=off", "-DRT_CULL_TEST_WITHOUT_MARGIN", "-I" + os.path.join(ROOT, "include"), src,
+                           "-L" + libdir, "-lrt_amd", "-Wl,-rpath," + libdir, "-o", exe])
+    out = subprocess.run([exe, "random", "1000000", "1"], stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, text=True, timeout=300)
+    os.remove(exe)
+    last = out.stdout.strip().splitlines()[-1]
+    assert out.returncode == 1 and int(last.split()[-1]) > 100, last
