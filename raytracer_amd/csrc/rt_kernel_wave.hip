@@ -365,9 +365,11 @@ __device__ __forceinline__ void trace_wave(const float4* __restrict__ nodes, int
     // never tested), s71 index of child 0, s[72:73] lanes that entered the branch, s[74:75] those of them still
     // undecided, s[76:77] undecided lanes of the wave, s78 child whose record is in s[84:91], s79/s80 links of the child
     // just tested, s81 byte offset, s[82:83] node array, s[92:93] triangle array, s[94:95] accepted lanes, s[96:97] undecided lanes,
-    // s[28:29] triangle candidates, s20 / s21 byte offsets of the triangle record under test and the one behind it, s22 offset
-    // behind the leaf's last record, s[24:25] lanes
-    // whose hit changed in the leaf, s30 reason / re-entry, s31 id of the candidate triangle; v[40:59] the ray
+    // s[28:29] triangle candidates, s20 / s21 byte offsets of the triangle record under test and the next one to be tested, s22 offset
+    // behind the leaf's last record (in a leaf whose triangles were put in front of the wave's bundle first: scratch), s[24:25] lanes
+    // whose hit changed in the leaf, s30 reason / re-entry (2 / 3: which of the two leaf loops), s31 id of the candidate triangle,
+    // s19 byte offset of the RtCullRec array (0: no bundle), s[98:99] within such a leaf the triangles still to be tested (outside
+    // the block they wait in lanes 62 / 63 of v60), ten scalar operands for the bundle; v[40:59] the ray
     // (origin, negated direction in the pairs the first stage multiplies, inverse direction, e * inv, margin terms,
     // closest hit so far, shadow-ray length), v[60:63] the wave's stack, v32 v33 v35 v36 determinant and numerators
     // of a candidate, v34 v37:v39 v64:v79 scratch.
@@ -834,6 +836,7 @@ __device__ __forceinline__ void trace_wave(const float4* __restrict__ nodes, int
 // A direction component so small that its inverse overflows (or a NaN) cannot feed the fused plane distances: such a
 // lane walks with a NaN inverse direction, which the conservative classification can decide nothing about - every node
 // test of the lane goes to the exact test, which does not use the inverse.
+template <bool CULLABLE>
 __device__ __forceinline__ uint64_t trace_class(const float4* __restrict__ nodes, int n_wnodes, const float4* __restrict__ tri_leaf,
                                                 const RtSphere* __restrict__ spheres, int n_spheres, bool has_oct, bool want,
                                                 const RtVec3& e, const RtVec3& d, float stop_t, Hit& hit, WaveStack& st, float* bary_lds,
@@ -867,8 +870,8 @@ __device__ __forceinline__ uint64_t trace_class(const float4* __restrict__ nodes
         neg_eb = -rt_slab_margin_bound_fused(ra.x, ra.y, ra.z, ra.w, rb.x, rb.y, e, inv, fu, hit.t);
       }
       RtBundle bundle = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-      const uint32_t cull = (cull_offset != 0u && wave_bundle(cls, e, d, stop_t, bundle, cull_r0_max, cull_ksp_max)) ? cull_offset : 0u;
-      after = walk_asm<true>(vnodes, variant, zpat, tri_leaf, top_first, rem, cls, e, d, inv, fu.c, neg_eb, stop_t, hit, st, bary_lds, cull, bundle RT_WORK_ARG);
+      const uint32_t cull = (CULLABLE && cull_offset != 0u && wave_bundle(cls, e, d, stop_t, bundle, cull_r0_max, cull_ksp_max)) ? cull_offset : 0u;
+      after = walk_asm<CULLABLE>(vnodes, variant, zpat, tri_leaf, top_first, rem, cls, e, d, inv, fu.c, neg_eb, stop_t, hit, st, bary_lds, cull, bundle RT_WORK_ARG);
     }
   }
   if (n_spheres > 0 && after) {
@@ -1169,13 +1172,15 @@ __global__ __launch_bounds__(RT_WBLOCK, (BOUNCE && !QPRIMARY) ? RT_WAVES_PER_SIM
   float tr_stop = -1.f;     // >= 0: shadow ray, length to the light
   int phase;
   constexpr bool wavefront = BOUNCE && QUEUES;                // bounce rays leave through the queue
-  // every ray through the assembly walk, class by class (trace_class)?  The variants with bounce rays keep the general
-  // walk for their mixed waves (measured with all variants class by class: glass bunny 1920x1080 3.23 -> 3.55 ms, 4K and
-  // the mirror scenes within 1 %).
+  // every ray through the assembly walk, class by class (trace_class)?  The variants with bounce rays on the lanes' stacks keep
+  // the general walk for their mixed waves (measured with all variants class by class, before the queues had launches of
+  // their own: glass bunny 1920x1080 3.23 -> 3.55 ms, 4K and the mirror scenes within 1 %); the launches that render a
+  // queue go class by class - their rays are ordered by direction class, so few waves are mixed (glass bunny 512x512
+  // 1.94 -> 1.87 ms, 1920x1080 2.83 -> 2.77, 4K unchanged).
 #ifdef RT_NO_ASM_WALK
   constexpr bool CLASSES = false;
 #else
-  constexpr bool CLASSES = (!BOUNCE || QPRIMARY) && !COUNT && !RT_PATHS_ON;
+  constexpr bool CLASSES = (!BOUNCE || wavefront) && !COUNT && !RT_PATHS_ON;
 #endif
   constexpr bool queued = wavefront && !QPRIMARY;   // this launch renders a queue of bounce rays, one per lane
   // Measurement build (tools/build_variant.sh lanes -DRT_LANE_WALK): the rays of a queue walked lane by lane (trace_lanes)
@@ -1289,7 +1294,7 @@ __global__ __launch_bounds__(RT_WBLOCK, (BOUNCE && !QPRIMARY) ? RT_WAVES_PER_SIM
       if (LANES) trace_lanes(nodes, LATE(node_skip), tri_leaf, spheres, n_spheres, has_oct != 0, want, tr_e, tr_d, stop_t, h);
       else if (CLASSES) {
         float* const bary = parked + (SW + 4) * RT_WBLOCK + (RT_WBLOCK == 64 ? 0 : (TID() & ~63));   // the wave's columns of the two barycentric words
-        traced = in_mask(trace_class(nodes, n_wnodes, tri_leaf, spheres, n_spheres, has_oct != 0, want, tr_e, tr_d, stop_t, h, st, bary, LATE(cull_offset), LATE(cull_r0_max), LATE(cull_ksp_max) RT_WORK_ARG));
+        traced = in_mask(trace_class<!queued>(nodes, n_wnodes, tri_leaf, spheres, n_spheres, has_oct != 0, want, tr_e, tr_d, stop_t, h, st, bary, LATE(cull_offset), LATE(cull_r0_max), LATE(cull_ksp_max) RT_WORK_ARG));
         asm volatile("" ::: "memory");
         h.bet = bary[LANE()]; h.gam = bary[RT_WBLOCK + LANE()];   // (only meaningful, and only used, when a triangle was hit)
       }
