@@ -100,8 +100,7 @@ __device__ __forceinline__ int fresh_lane_id() {
 // would keep a 64-bit per-lane value alive wherever it is used.)
 __device__ __forceinline__ bool in_mask(uint64_t mask) { return __builtin_amdgcn_inverse_ballot_w64(mask); }
 
-// The bundle of the rays in `cls` (rt_math.h: RtBundle, rt_cull_test) for the walk's triangle skipping, left in lanes
-// 32 .. 41 of the stack's first register (the stack itself never gets beyond lane 19).  The point the lines pass close
+// The bundle of the rays in `cls` (rt_math.h: RtBundle, rt_cull_test) for the walk's triangle skipping.  The point the lines pass close
 // to is taken from the first ray: its origin, or for a shadow ray the point at the light's distance (the rays towards a
 // point light all pass through the light; primary rays share the eye; parallel rays only need some point).  Returns
 // false when the bundle is too wide to rule anything out (rays that have little in common): the walk then tests every

@@ -595,7 +595,8 @@ inline RtCullRec rt_cull_record(const float* v0, const float* e1, const float* e
 }
 #endif
 
-// A ray's share of the bundle around axis (o, a): its line's distance from o, its origin's distance from o, |d - a|.
+// A ray's share of the bundle around axis (o, a): its line's distance from o (for a unit direction; rt_bundle_finish allows for
+// the rest), its origin's distance from o, |d - a|.
 // (The distance comes from the cross product: a difference of squares would lose it for a far-away o.)
 RT_HD void rt_bundle_lane(const RtVec3& o, const RtVec3& a, const RtVec3& e, const RtVec3& d, float& r0, float& bw, float& k) {
   const RtVec3 w = {o.x - e.x, o.y - e.y, o.z - e.z};
@@ -608,11 +609,12 @@ RT_HD void rt_bundle_lane(const RtVec3& o, const RtVec3& a, const RtVec3& e, con
 RT_HD RtBundle rt_bundle_finish(const RtVec3& o, const RtVec3& a, float r0, float bw, float k) {
   RtBundle B;
   B.ox = o.x; B.oy = o.y; B.oz = o.z; B.ax = a.x; B.ay = a.y; B.az = a.z;
-  B.r0 = fmaf(r0, 1.001f, fmaf(bw, 0x1p-18f, 1e-6f));
   // (a direction need not be a unit vector: |d| >= 1 - k, so a line reaches the ball (c, R') within (|c - o| + R') / (1 - k) of
-  //  its point nearest o; that factor goes into the spread)
+  //  its point nearest o, and its distance from o is at most |(o - eye) x d| / (1 - k); that factor goes into spread and r0)
   const float ks = fmaf(k, 1.001f, 0x1p-18f);
-  B.ksp = ks < 0.9f ? ks / (1.f - ks) * 1.000001f : __builtin_inff();
+  const float grow = ks < 0.9f ? 1.000001f / (1.f - ks) : __builtin_inff();
+  B.r0 = fmaf(r0, 1.001f, fmaf(bw, 0x1p-18f, 1e-6f)) * grow;
+  B.ksp = ks * grow;
   B.k1 = (1.f + B.ksp) * 1.000001f;
   B.bw = fmaf(bw, 1.001f, 1e-4f);
   return B;

@@ -7,7 +7,8 @@
 //       above the scene and straight up, as bundles; every triangle of every leaf some ray of the bundle enters.
 //   host_cull_check random <count> <seed>
 //       adversarial pairs: single rays and narrow bundles that miss a random triangle (slivers, specks, large ones) by
-//       10^-7 .. 10^-1, rays in the triangle's plane and parallel to its edges, origins inside the plane.
+//       10^-7 .. 10^-1, rays in the triangle's plane and parallel to its edges, origins inside the plane, directions that are
+//       not quite unit vectors.
 // Prints "checked <pairs> skipped <n> (<pct>%) accepted <a> mismatches <m>" (scene mode: also the leaf visits left without a
 // triangle) and exits non-zero when m > 0.
 #include <cmath>
@@ -169,7 +170,8 @@ static int run_random(int ac, char** av) {
       for (int k = 0; k < 3; k++) d[k] = a * e1[k] + b * e2[k] + tilt * size * n[k] / nl;
     }
     const double dl = sqrt(d[0] * d[0] + d[1] * d[1] + d[2] * d[2]); if (!(dl > 0)) continue;
-    const RtVec3 df = rt_normalized({(float)d[0], (float)d[1], (float)d[2]});
+    RtVec3 df = rt_normalized({(float)d[0], (float)d[1], (float)d[2]});
+    if (rng() % 8 == 0) { const float sc = (float)U(0.9, 1.1); df = {df.x * sc, df.y * sc, df.z * sc}; }   // a direction that is not a unit vector
     const double back = U(0.0, 40.0);
     // a bundle: the ray alone, or with neighbours through a common point / parallel to it
     std::vector<Ray> rays;
