@@ -776,6 +776,7 @@ void load_scene_into(rt_scene& sc, const std::string& scene_path, const std::str
     // RT_LEAF_PAD extra records at the end, so that the traversal may always request "the next one" (the walk's
     // end-of-leaf marker stands for record 63 of the leaf).  Behind them, in the same array, one RtCullRec per
     // record (and as many pads: lane k of a wave reads record k of the leaf it enters, whatever the leaf's length).
+    static_assert(RT_LEAF_CAP < 63 && RT_LEAF_PAD >= 64, "the walk keeps a leaf's triangles in a 64-bit mask whose bit 63 marks the end");
     const size_t n_rec = sc.leaf_refs.size() + RT_LEAF_PAD;
     sc.tri_leaf.assign(n_rec + (n_rec * sizeof(RtCullRec) + sizeof(RtTriLeaf) - 1) / sizeof(RtTriLeaf), RtTriLeaf{});
     sc.cull_offset = (uint32_t)(n_rec * sizeof(RtTriLeaf));
