@@ -417,10 +417,12 @@ int launch_render(const SceneArrays& S, RenderCtx& ctx, RowMap rows, uint8_t* d_
   if (timed) { HIP_TRY(hipEventCreate(&ev.a)); HIP_TRY(hipEventCreate(&ev.b)); HIP_TRY(hipEventRecord(ev.a, stream)); }
   if (rows.n_local > 0) {
     if (!(flags & RT_RENDER_LITERAL)) {
-      // Small frames are cut into 4x4 tiles where that was measured to pay: heavy meshes when the 8x8 tiles do not even
-      // fill the chip's wave slots (256 CUs x 4 SIMDs x 5), and scenes with mirrors or glass over a mesh, whose frame time
-      // is the longest chain of dependent walks of one tile, up to about 720p.  (meshDragon 512x512: 1.50 -> 1.18 ms,
-      // glass bunny 512x512: 7.8 -> 4.8 ms; light scenes and larger frames are faster on 8x8 tiles.)
+      // Small frames are cut into 4x4 tiles where that was measured to pay: heavy meshes up to about 1366x768 (a small frame
+      // ends when its longest waves end, and the sixteen rays of a 4x4 tile form a narrower bundle, which rules out more of a
+      // leaf's triangles, and walk a smaller union of subtrees: meshDragon 640x480 1.06 -> 0.71 ms, 1024x768 0.89 -> 0.75,
+      // 1280x720 0.93 -> 0.73; from 1600x900 on the 8x8 tiles win, 0.86 against 0.94 ms), and scenes with mirrors or glass over
+      // a mesh, whose frame time is the longest chain of dependent walks of one tile, up to about 720p (glass bunny 512x512:
+      // 7.8 -> 4.8 ms on the stacks; light scenes and larger frames are faster on 8x8 tiles).
       const long tiles = ((long)(S.view.cam.width + 7) / 8) * ((rows.n_local + 7) / 8);
       static const int forced = getenv("RT_AMD_TILE") ? atoi(getenv("RT_AMD_TILE")) : 0;   // 4 or 8: measurements
       const bool mesh = S.info.n_triangles > 0;
@@ -428,7 +430,7 @@ int launch_render(const SceneArrays& S, RenderCtx& ctx, RowMap rows, uint8_t* d_
       //  tiles dealt out from the middle of the picture that one is 2 to 8 % faster on the large tiles at 512x512 .. 1280x720)
       const bool from_queues = !S.view.textures && ((flags & RT_RENDER_QUEUED) || (!(flags & RT_RENDER_STACKED) && S.dielectric_mesh));
       rows.small = forced ? (forced == 4)
-                          : ((S.info.n_triangles >= 20000 && tiles < 5120) ||
+                          : ((S.info.n_triangles >= 20000 && tiles < 16000) ||
                              (S.info.has_bounce_materials && mesh && tiles < 16384 && !from_queues));
     }
     if (flags & RT_RENDER_LITERAL) rt_launch_lane_kernel(S.view, rows, bounce, count, d_rgb, d_ids, d_t, d_counters, stats != nullptr, stream);
