@@ -558,3 +558,48 @@ def test_skipping_triangles_on_small_meshes_too():
     out = subprocess.run([sys.executable, "-c", _CULL_CHILD], env=env, capture_output=True, text=True, timeout=110)
     assert out.returncode == 0, out.stderr[-2000:]
     assert out.stdout.strip().splitlines() == want
+
+
+@pytest.mark.gpu
+def test_skipping_triangles_from_random_viewpoints(tmp_path):
+    # meshDragon and the glass bunny seen from seeded random viewpoints (far, close, grazing along the floor, from below the
+    # horizon line of the mesh) under random point and directional lights: with and without the triangle skip the same
+    # bytes, ids, distances and ray counts
+    import json
+    import os
+    rng = np.random.RandomState(20261112)
+    assets = rt.ASSETS
+    os.symlink(os.path.join(assets, "meshes"), str(tmp_path / "meshes"))
+    os.symlink(os.path.join(assets, "resources.json"), str(tmp_path / "resources.json"))
+    os.mkdir(str(tmp_path / "scenes"))
+    seen = 0
+    for name, n_views in (("meshDragon", 10), ("meshTransparentBunny", 4)):
+        with open(os.path.join(assets, "scenes", name + ".json")) as f:
+            scene = json.load(f)
+        for view in range(n_views):
+            sc = json.loads(json.dumps(scene))
+            dist = float(rng.choice([4.0, 9.0, 18.0, 35.0]))
+            az, el = rng.uniform(0, 2 * np.pi), rng.choice([0.02, 0.15, 0.5, 1.1])
+            target = [float(rng.uniform(-2, 2)), float(rng.uniform(0.5, 6)), float(rng.uniform(-2, 2))]
+            sc["camera"]["position"] = [target[0] + dist * np.cos(el) * np.cos(az), target[1] + dist * np.sin(el), target[2] + dist * np.cos(el) * np.sin(az)]
+            sc["camera"]["target"] = target
+            sc["camera"]["fov"] = float(rng.choice([20.0, 45.0, 80.0]))
+            for l in sc["lights"]:
+                if l["__type__"] == "point_light":
+                    l["position"] = [float(rng.uniform(-15, 15)), float(rng.uniform(1, 20)), float(rng.uniform(-15, 15))]
+                if l["__type__"] == "directional_light":
+                    d = rng.normal(size=3); d[1] = -abs(d[1]) - 0.05
+                    l["direction"] = [float(x) for x in d]
+            path = str(tmp_path / "scenes" / ("%s_view%d.json" % (name, view)))
+            with open(path, "w") as f:
+                json.dump(sc, f)
+            w, h = [(640, 360), (333, 187), (1280, 720)][view % 3]
+            ds = rt.DeviceScene(rt.Scene(path, w, h, 3, base_dir=str(tmp_path)))
+            a, ida, ta, sa = ds.render_host()
+            b, idb, tb, sb = ds.render_host(flags=rt.RT_RENDER_EVERY_TRIANGLE)
+            assert np.array_equal(a, b) and np.array_equal(ida, idb) and np.array_equal(ta.view(np.uint32), tb.view(np.uint32)), (name, view)
+            for k in ("rays", "shadow_rays", "rays_traced"):
+                assert sa[k] == sb[k], (name, view, k, sa[k], sb[k])
+            seen += int((ida >= 0).mean() > 0.05)   # (a twentieth of the pixels or more show a triangle)
+            ds.close()
+    assert seen >= 10
