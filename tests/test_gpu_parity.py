@@ -453,7 +453,8 @@ def test_gather_and_unpack_entry_points_with_a_world_of_one():
 @pytest.mark.parametrize("name", ALL_SCENES)
 def test_against_committed_golden_fixtures(name):
     # tests/golden/scenes_128: ids, distances, RGB and counters of the CPU oracle as rendered where the fixtures were made
-    # (tools/make_goldens.py).  The HIP path is held to them directly, and so is the oracle as built on this machine:
+    # (tools/make_goldens.py).  They are the oracle's own output - a guard against drift between machines and builds, not a
+    # second pin of the oracle: what pins the oracle is tests/test_oracle_pins.py.  The HIP path is held to them directly, and so is the oracle as built on this machine:
     # a drift of the oracle or of the host's libm between machines shows here instead of cancelling out.
     import json
     import os
@@ -463,11 +464,18 @@ def test_against_committed_golden_fixtures(name):
         man = json.load(f)["scenes"][name]
     g = np.load(os.path.join(gdir, name + ".npz"))
     w, h, depth = man["width"], man["height"], man["depth"]
-    rgb, ids, ts, st = rt.DeviceScene(rt.Scene("scenes/%s.json" % name, w, h, depth)).render_host(flags=rt.RT_RENDER_COUNT_TESTS)
+    ds = rt.DeviceScene(rt.Scene("scenes/%s.json" % name, w, h, depth))
+    rgb, ids, ts, st = ds.render_host(flags=rt.RT_RENDER_COUNT_TESTS)
     assert np.array_equal(ids, g["ids"]), "primary hit ids differ from the fixture on %d pixels" % int((ids != g["ids"]).sum())
     assert np.array_equal(ts.view(np.uint32), g["t_bits"]), "primary hit distances differ from the fixture"
     frac_ok, n_diff, max_diff = _rgb_close(rgb, g["rgb"])
     assert frac_ok >= 0.999, (name, frac_ok, n_diff, max_diff)
+    # the production variant (assembly walk, shadow rays stopped at their first blocker, leaf triangles ruled out per wave) is
+    # held to the same fixture directly, not only through its equality with the instrumented variant elsewhere in this file
+    rgb_p, ids_p, ts_p, _ = ds.render_host()
+    assert np.array_equal(ids_p, g["ids"]) and np.array_equal(ts_p.view(np.uint32), g["t_bits"]), "production variant: ids / distances differ from the fixture"
+    p_ok, p_diff, p_max = _rgb_close(rgb_p, g["rgb"])
+    assert p_ok >= 0.999, ("production variant", name, p_ok, p_diff, p_max)
     if name != "meshTransparentBunny":
         for k in COUNTER_KEYS:
             assert st[k] == man["counters"][k], (name, k, st[k], man["counters"][k])
