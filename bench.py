@@ -271,12 +271,21 @@ def main():
                 roofline["executed_tflops"] = prof["executed_fp32_flop_per_launch"] / (kernel_ms * 1e-3) / 1e12
                 roofline["executed_frac"] = roofline["executed_tflops"] / PEAK_FP32_TFLOPS
                 cycles = kernel_ms * 1e-3 * 2.4e9 * 1024      # SIMD-cycles of the launch at the 2.4 GHz peak clock
+                roofline["executed_frac_of_fma_free_peak"] = roofline["executed_tflops"] / (PEAK_FP32_TFLOPS / 2)   # the reference arithmetic has no fused multiply-adds
                 if "SQ_INSTS_VALU" in c:
                     roofline["valu_insts_per_launch"] = c["SQ_INSTS_VALU"]
-                    # priced at 4 cycles per wave64 vector instruction: an upper bound (measured in isolation a two-operand one takes
-                    # about 2.7 cycles of its SIMD, a packed or three-source one 4.3-4.8), so the figure can exceed 1
-                    roofline["valu_issue_busy"] = c["SQ_INSTS_VALU"] * 4 / cycles
-                    roofline["valu_issue_busy_is"] = "SQ_INSTS_VALU x 4 cycles / (SIMDs x kernel time x 2.4 GHz): an upper bound, simple instructions issue faster"
+                    # Vector issue, priced per instruction class at the rates measured in isolation on this chip
+                    # (profiles/r1_valu_issue_rates.txt, two or more waves per SIMD): a two-operand instruction 2.7 cycles of its
+                    # SIMD, a three-source one (the fused multiply-adds of the node scan) 4.3, a transcendental one four times a
+                    # simple one.  The counters single out only the FP classes; every other vector instruction (compares, selects,
+                    # min3 / med3, moves, lane reads) is priced as a two-operand one, so the figure is a LOWER bound of the
+                    # issue port's occupation - and at most 1 by construction of the rates.
+                    fma, trans = c.get("SQ_INSTS_VALU_FMA_F32", 0), c.get("SQ_INSTS_VALU_TRANS_F32", 0)
+                    issue_cycles = 4.3 * fma + 4 * 2.7 * trans + 2.7 * (c["SQ_INSTS_VALU"] - fma - trans)
+                    roofline["valu_issue_busy_min"] = issue_cycles / cycles
+                    roofline["valu_issue_busy_min_is"] = "sum over instruction classes of count x cycles measured per class (profiles/r1_valu_issue_rates.txt) / (SIMDs x kernel time x 2.4 GHz); unclassified instructions priced at the cheapest class: a lower bound"
+                if "SQ_WAIT_INST_ANY" in c and c.get("SQ_WAVE_CYCLES"):
+                    roofline["wave_cycles_waiting_frac"] = c["SQ_WAIT_INST_ANY"] / c["SQ_WAVE_CYCLES"]   # wave-cycles spent waiting for any instruction to complete or issue
                 if "SQ_INSTS_SALU" in c:
                     roofline["salu_smem_insts_per_launch"] = c["SQ_INSTS_SALU"] + c.get("SQ_INSTS_SMEM", 0)
                     roofline["scalar_issue_busy"] = roofline["salu_smem_insts_per_launch"] * 4 / cycles   # one scalar issue per SIMD every 4 cycles

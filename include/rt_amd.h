@@ -100,6 +100,51 @@ int rt_scene_load(const char* scene_json, const char* resources_json, const char
 void rt_scene_destroy(rt_scene* s);
 int rt_scene_get_info(const rt_scene* s, rt_scene_info* out);
 
+/* ---- a scene from arrays in memory ----------------------------------------------------------------------------------
+ * For a caller that already holds the scene: the reference's own parse() (parsing/parsing.cu:145-473) and host model,
+ * say, whose main() hands camera, lights, objects and meshes to its *GPUAdapter classes (main.cu:18-23).  The structs
+ * below are the reference's device PODs with indices in place of pointers; the caller keeps its arrays, the library
+ * copies what it needs and builds the octree itself (replaces main.cu:20-32, mesh.cu:65-97,116-134, object.cu:16-20,
+ * lights.cu:232-258, camera.cu:45-74's upload).  Floats are taken as they are: whoever fills the structs does the
+ * reference's host arithmetic (camera basis, mesh transforms, normals), the library does none of it again. */
+typedef struct rt_camera_desc {   /* DCamera (camera/camera.cuh:10-17) as Camera::buildDCamera fills it */
+  float u[3], v[3], w[3], pos[3];
+  float left, right, bottom, top;
+  float scene_refr, bg_col[3];
+  int32_t width, height, ray_depth, shadows;
+} rt_camera_desc;
+typedef struct rt_light_desc {    /* DLight (lights/lights.cuh:10-13); type in DLigType's order: 0 PUNCTUAL 1 SPOT 2 AMBIENT 3 DIRECTIONAL */
+  float col[3], pos[3], dir[3], angle;
+  int32_t type;
+} rt_light_desc;
+typedef struct rt_material_desc { /* DMaterial (material/material.cuh:12-15); type in DMatType's order: 0 LAMBERT 1 PHONG 2 REFLECTIVE 3 DIELECTRIC */
+  float col[3], att[3], param;    /* param: shininess (PHONG) or refraction index (DIELECTRIC) */
+  int32_t type;                   /* 4 (TEXTURE) is refused: the reference has no behaviour for it; texture materials come in through rt_scene_load */
+} rt_material_desc;
+typedef struct rt_sphere_desc {   /* DSphere (spheres/spheres.cuh:7-11); its materials are mat_index[mat_first .. mat_first + mat_count) */
+  float c[3], r;
+  int32_t mat_first, mat_count;
+} rt_sphere_desc;
+typedef struct rt_scene_desc {
+  rt_camera_desc camera;
+  int32_t n_lights, n_materials, n_mat_index, n_spheres, n_meshes, n_triangles;
+  const rt_light_desc* lights;
+  const rt_material_desc* materials;
+  const int32_t* mat_index;        /* concatenated material lists of spheres and meshes: indices into materials[] */
+  const rt_sphere_desc* spheres;   /* in allObjects order (object.cu:16-20): sphere s has primitive id -2 - s */
+  const int32_t* mesh_mat_first;   /* per mesh: its material list in mat_index (mesh.cu:50-63) */
+  const int32_t* mesh_mat_count;
+  /* triangles in MeshGPUAdapter's order (meshes in scene order, faces in file order: mesh.cu:116-134); triangle i has primitive id i */
+  const float* tri_verts;          /* n_triangles * 9: DTriangle::v */
+  const float* tri_normals;        /* n_triangles * 9: DTriangle::n */
+  const float* tri_uv;             /* n_triangles * 6: DTriangle::uv, or NULL (the path never reads them without texture materials) */
+  const int32_t* tri_mesh;         /* n_triangles: index of the triangle's mesh */
+} rt_scene_desc;
+int rt_scene_create(const rt_scene_desc* desc, rt_scene** out);
+/* The description of a scene made either way, pointing into memory the rt_scene owns (valid until rt_scene_destroy):
+ * rt_scene_create of it gives a scene that renders the same bytes.  Scenes with texture materials: RT_ERR_LIMIT. */
+int rt_scene_describe(rt_scene* s, rt_scene_desc* out);
+
 /* Octree in depth-first preorder (children 0..7), the order
  * OctBranch::buildDNodes walks (octtree/octtree.cu:64-87).  kind[i] = -1 for a
  * branch else the leaf's triangle count; bounds[i*6..] = ini xyz, end xyz;
@@ -157,7 +202,12 @@ int rt_render_rows(rt_dscene* d, int row_begin, int row_end, uint8_t* d_rgb, int
  * RT_RENDER_STACKED, which needs the counters only; every other scene is accepted at any size.  Each GPU has ONE such array, shared by all
  * rt_dscene handles of the process: calls that overlap on one GPU race on it (the counters and queue fills are cleared
  * by each call that uses them, so calls in sequence are independent).  Without `stats`, and for scenes not rendered
- * from queues, the call only enqueues kernels and memsets on `stream`. */
+ * from queues, the call only enqueues kernels and memsets on `stream`.
+ * What the library does ahead of the call so that nothing is left to set up inside it: rt_scene_upload (and
+ * rt_device_prepare) load the code objects of every kernel file on the device and take the array's address.  What it
+ * cannot do ahead: the HIP runtime sizes the private (spill) memory of a stream's hardware queue when a kernel that needs
+ * some is first launched on that stream; a caller for whom even that matters launches one throw-away render on the
+ * stream first. */
 int rt_render_rows_static(rt_dscene* d, int row_begin, int row_end, uint8_t* d_rgb, int32_t* d_ids, float* d_t,
                           void* stream, unsigned flags, rt_stats* stats);
 
@@ -199,6 +249,23 @@ int rt_unpack_bands(const uint8_t* d_gathered, size_t bytes_per_rank, int nranks
  * summed over the devices; kernel_ms = first launch to last tile in place on the first device, copy_ms = the copy out. */
 int rt_render_frame_gathered(rt_dscene* const* scenes, rt_comm* const* comms, int n, int band_rows, uint8_t* h_rgb,
                              unsigned flags, rt_stats* stats);
+/* Frames in flight: a pipeline set up once - per slot (a frame in flight) and device a render context on the uploaded
+ * scene, a stream and a band tile; on scenes[0]'s device the gathered tiles, the frame and a page-locked host copy of it -
+ * so that rendering a frame creates and allocates nothing: rt_frame_enqueue renders the bands of every device, gathers,
+ * unpacks and starts the copy to the host, all asynchronously (scenes whose bounce rays go through queues read one word
+ * back per device and frame, see rt_render_rows), rt_frame_wait returns when the slot's frame is in host memory.  With
+ * 2-3 slots the next frames fill the tail of long waves a short frame ends on (what one GPU of eight renders is short):
+ * pass RT_RENDER_STRIPS then.  comms == NULL with n == 1: one GPU, no exchange, RCCL is not loaded.  The reference renders one
+ * frame per process and copies it back synchronously (main.cu:44-57); this replaces that for callers with more to render.
+ * One thread at a time per rt_frame_ctx; the scenes and communicators must outlive it. */
+typedef struct rt_frame_ctx rt_frame_ctx;
+int rt_frame_ctx_create(rt_dscene* const* scenes, rt_comm* const* comms, int n, int band_rows, int slots, rt_frame_ctx** out);
+void rt_frame_ctx_destroy(rt_frame_ctx* f);
+int rt_frame_enqueue(rt_frame_ctx* f, int slot, unsigned flags);
+/* *h_rgb: the slot's page-locked frame (W*H*3 bytes, valid until the slot is enqueued again); *frame_ms: first launch to
+ * the frame in host memory, from events on the first device's stream.  Either may be NULL. */
+int rt_frame_wait(rt_frame_ctx* f, int slot, const uint8_t** h_rgb, float* frame_ms);
+
 /* Decode a texture image (8-bit non-interlaced PNG, baseline JPEG) to RGB8, row 0 on top: the loader behind the
  * `textures` of resources.json.  The reference's own loader is an unfinished stub (material/material.cu:276-289).
  * rgb == NULL: only width and height are returned; else `capacity` must be at least width * height * 3. */

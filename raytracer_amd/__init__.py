@@ -29,7 +29,7 @@ RT_RENDER_EVERY_TRIANGLE = 64
 
 # Every symbol include/rt_amd.h declares.
 ABI_SYMBOLS = (
-    "rt_scene_load", "rt_scene_destroy", "rt_scene_get_info", "rt_scene_dump_tree", "rt_scene_dump_triangles",
+    "rt_scene_load", "rt_scene_create", "rt_scene_describe", "rt_scene_destroy", "rt_scene_get_info", "rt_scene_dump_tree", "rt_scene_dump_triangles",
     "rt_scene_dump_camera", "rt_device_prepare", "rt_scene_upload", "rt_dscene_destroy", "rt_dscene_fork", "rt_render_rows", "rt_render_rows_static", "rt_render_rows_host",
     "rt_host_alloc", "rt_host_free", "rt_band_count", "rt_render_bands", "rt_dscene_get_info",
     "rt_comm_unique_id", "rt_comm_init_rank", "rt_comm_init_all", "rt_comm_destroy", "rt_comm_group_begin", "rt_comm_group_end",
@@ -66,6 +66,35 @@ class Stats(C.Structure):
         return d
 
 
+class CameraDesc(C.Structure):
+    """rt_camera_desc: the reference's DCamera (camera/camera.cuh:10-17)."""
+    _fields_ = [("u", C.c_float * 3), ("v", C.c_float * 3), ("w", C.c_float * 3), ("pos", C.c_float * 3),
+                ("left", C.c_float), ("right", C.c_float), ("bottom", C.c_float), ("top", C.c_float),
+                ("scene_refr", C.c_float), ("bg_col", C.c_float * 3),
+                ("width", C.c_int32), ("height", C.c_int32), ("ray_depth", C.c_int32), ("shadows", C.c_int32)]
+
+
+class LightDesc(C.Structure):
+    _fields_ = [("col", C.c_float * 3), ("pos", C.c_float * 3), ("dir", C.c_float * 3), ("angle", C.c_float), ("type", C.c_int32)]
+
+
+class MaterialDesc(C.Structure):
+    _fields_ = [("col", C.c_float * 3), ("att", C.c_float * 3), ("param", C.c_float), ("type", C.c_int32)]
+
+
+class SphereDesc(C.Structure):
+    _fields_ = [("c", C.c_float * 3), ("r", C.c_float), ("mat_first", C.c_int32), ("mat_count", C.c_int32)]
+
+
+class SceneDesc(C.Structure):
+    """rt_scene_desc: a scene as flat arrays in the caller's memory (include/rt_amd.h)."""
+    _fields_ = [("camera", CameraDesc)] + [(n, C.c_int32) for n in ("n_lights", "n_materials", "n_mat_index", "n_spheres", "n_meshes", "n_triangles")] + [
+        ("lights", C.POINTER(LightDesc)), ("materials", C.POINTER(MaterialDesc)), ("mat_index", C.POINTER(C.c_int32)),
+        ("spheres", C.POINTER(SphereDesc)), ("mesh_mat_first", C.POINTER(C.c_int32)), ("mesh_mat_count", C.POINTER(C.c_int32)),
+        ("tri_verts", C.POINTER(C.c_float)), ("tri_normals", C.POINTER(C.c_float)), ("tri_uv", C.POINTER(C.c_float)),
+        ("tri_mesh", C.POINTER(C.c_int32))]
+
+
 _lib = None
 
 
@@ -95,6 +124,8 @@ def lib():
         _share_hip_runtime_with_torch()
         L = C.CDLL(LIB_PATH)
         L.rt_scene_load.argtypes = [C.c_char_p, C.c_char_p, C.c_char_p, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_void_p)]
+        L.rt_scene_create.argtypes = [C.POINTER(SceneDesc), C.POINTER(C.c_void_p)]
+        L.rt_scene_describe.argtypes = [C.c_void_p, C.POINTER(SceneDesc)]
         L.rt_scene_destroy.argtypes = [C.c_void_p]
         L.rt_scene_destroy.restype = None
         L.rt_scene_get_info.argtypes = [C.c_void_p, C.POINTER(SceneInfo)]
@@ -177,6 +208,21 @@ class Scene:
         _check(lib().rt_scene_load(asset(scene).encode(), res.encode(), base.encode(), width, height, max_depth,
                                    C.byref(self.h)))
         self.width, self.height, self.max_depth = width, height, max_depth
+
+    @classmethod
+    def from_desc(cls, desc):
+        """A scene from arrays in memory (rt_scene_create); the library copies what it needs."""
+        self = cls.__new__(cls)
+        self.h = C.c_void_p()
+        _check(lib().rt_scene_create(C.byref(desc), C.byref(self.h)))
+        self.width, self.height, self.max_depth = desc.camera.width, desc.camera.height, desc.camera.ray_depth
+        return self
+
+    def describe(self):
+        """This scene as an rt_scene_desc whose pointers reach into the scene's own memory (valid while the scene lives)."""
+        d = SceneDesc()
+        _check(lib().rt_scene_describe(self.h, C.byref(d)))
+        return d
 
     def close(self):
         if getattr(self, "h", None):

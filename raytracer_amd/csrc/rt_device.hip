@@ -4,6 +4,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <algorithm>
+#include <atomic>
 #include <cstring>
 #include <memory>
 #include <mutex>
@@ -142,9 +143,14 @@ int arena_reserve(Arena& a, size_t bytes, const char* what) {
     rt_set_error(std::string(what) + ": needs " + std::to_string(bytes) + " bytes of scratch, the fixed arena holds " + std::to_string(a.bytes));
     return RT_ERR_LIMIT;
   }
-  (void)hipFree(a.base); a.base = nullptr; a.bytes = 0;
+  // the new arena first: when it cannot be had the old one (and the counters every launch is handed) stays as it is
   void* p = nullptr;
-  HIP_TRY(hipMalloc(&p, bytes));
+  if (hipMalloc(&p, bytes) != hipSuccess) {
+    (void)hipGetLastError();
+    rt_set_error(std::string(what) + ": hipMalloc of " + std::to_string(bytes) + " bytes of scratch failed");
+    return RT_ERR_NOMEM;
+  }
+  (void)hipFree(a.base);
   a.base = (unsigned char*)p; a.bytes = bytes;
   return RT_OK;
 }
@@ -162,7 +168,7 @@ struct StaticScratch {
   unsigned char* ptr = nullptr;   // device address of `scratch` on this device
   void* landing = nullptr;        // page-locked host words the counters and the queue state are copied into
   TermPool pool;                  // (the array starts out zeroed, like a pool that was just cleared nowhere: see TermPool)
-  bool ready = false;
+  std::atomic<bool> ready{false};   // (read by rt_render_rows_static without the mutex)
 };
 StaticScratch g_static[RT_STATIC_MAX_DEVICES];
 std::mutex g_static_mutex;
@@ -173,6 +179,11 @@ int static_scratch_setup(int device) {
   std::lock_guard<std::mutex> lock(g_static_mutex);
   StaticScratch& S = g_static[device];
   if (S.ready) return RT_OK;
+  // every code object a render call can launch from is loaded now: the runtime loads one when a kernel of it is first
+  // asked for, which allocates, and the static entry point may be a process's very first render
+  HIP_TRY((hipError_t)rt_preload_wave_kernels());
+  HIP_TRY((hipError_t)rt_preload_lane_kernels());
+  HIP_TRY((hipError_t)rt_preload_queue_kernels());
   void* p = nullptr;
   HIP_TRY(hipGetSymbolAddress(&p, HIP_SYMBOL(scratch)));
   if (!S.landing) HIP_TRY(hipHostMalloc(&S.landing, RT_STATIC_LANDING_BYTES, hipHostMallocDefault));
@@ -205,8 +216,7 @@ extern "C" int rt_device_prepare(int device) {
   DeviceGuard g(device);
   HIP_TRY(g.err);
   HIP_TRY(hipFree(nullptr));   // (creates the device's context)
-  HIP_TRY((hipError_t)rt_preload_wave_kernels());
-  return static_scratch_setup(device);
+  return static_scratch_setup(device);   // (loads the code objects of every kernel file too)
 }
 
 extern "C" int rt_scene_upload(const rt_scene* s, int device, rt_dscene** out) {
@@ -408,6 +418,7 @@ int launch_render(const SceneArrays& S, RenderCtx& ctx, RowMap rows, uint8_t* d_
     const int rc = prepare_wavefront(S, ctx, rows, stream, &queued);
     if (rc != RT_OK) return rc;
   }
+  if (!ctx.arena.base || ctx.arena.bytes < RT_COUNTER_BYTES) { rt_set_error("render context without a counter arena"); return RT_ERR_DEVICE; }
   unsigned long long* const d_counters = (unsigned long long*)ctx.arena.base;
   // the counters are only read back for a caller that passes an rt_stats: no need to clear them for anybody else
   if (stats) HIP_TRY(hipMemsetAsync(d_counters, 0, RT_COUNTER_BYTES, stream));

@@ -12,6 +12,7 @@
 
 #include <chrono>
 #include <cstring>
+#include <memory>
 #include <mutex>
 #include <string>
 #include <thread>
@@ -281,5 +282,133 @@ extern "C" int rt_render_frame_gathered(rt_dscene* const* scenes, rt_comm* const
   }
   for (int r = 1; r < n; r++) { DeviceScope g(dev[r]); (void)hipStreamSynchronize(P[r].stream); }
   cleanup();
+  return RT_OK;
+}
+
+// ---- frames in flight ------------------------------------------------------------------------------------------------
+// A pipeline that is set up once and then renders frame after frame without creating anything: per slot (a frame in
+// flight) and device a render context on the uploaded scene (rt_dscene_fork), a stream and a band tile; on the first
+// device the gathered tiles, the frame in image order and a page-locked host copy of it, and two events.  A short frame
+// on one GPU of several ends on a few long waves while most of the chip idles; a second and third frame in flight fill
+// that tail, which is why the pipeline exists.
+struct rt_frame_ctx {
+  int n = 0, band_rows = 0, W = 0, H = 0;
+  size_t tile_bytes = 0, frame_bytes = 0;
+  std::vector<int> dev;
+  std::vector<rt_comm*> comms;      // empty: one device, no exchange
+  struct Slot {
+    std::vector<rt_dscene*> ctx;
+    std::vector<hipStream_t> stream;
+    std::vector<uint8_t*> local;    // (n > 1, or a communicator was given: the device's packed bands)
+    uint8_t* gathered = nullptr; uint8_t* image = nullptr; uint8_t* host = nullptr;
+    hipEvent_t begin = nullptr, end = nullptr;
+    bool busy = false;
+  };
+  std::vector<Slot> slot;
+};
+
+extern "C" void rt_frame_ctx_destroy(rt_frame_ctx* f) {
+  if (!f) return;
+  for (auto& S : f->slot) {
+    for (size_t r = 0; r < S.stream.size(); r++) {
+      DeviceScope g(f->dev[r]);
+      if (S.stream[r]) { (void)hipStreamSynchronize(S.stream[r]); (void)hipStreamDestroy(S.stream[r]); }
+      if (r < S.local.size()) (void)hipFree(S.local[r]);
+      if (r < S.ctx.size() && S.ctx[r]) rt_dscene_destroy(S.ctx[r]);
+    }
+    DeviceScope g(f->dev.empty() ? 0 : f->dev[0]);
+    (void)hipFree(S.gathered); (void)hipFree(S.image);
+    if (S.host) (void)hipHostFree(S.host);
+    if (S.begin) (void)hipEventDestroy(S.begin);
+    if (S.end) (void)hipEventDestroy(S.end);
+  }
+  delete f;
+}
+
+extern "C" int rt_frame_ctx_create(rt_dscene* const* scenes, rt_comm* const* comms, int n, int band_rows, int slots, rt_frame_ctx** out) {
+  if (!scenes || !out || n < 1 || slots < 1 || slots > 8 || band_rows < 1 || band_rows % RT_TILE_H || (n > 1 && !comms)) {
+    rt_set_error("rt_frame_ctx_create: bad argument (1..8 slots, band_rows a multiple of 16, a communicator per device when there are several)");
+    return RT_ERR_ARG;
+  }
+  *out = nullptr;
+  std::unique_ptr<rt_frame_ctx, void (*)(rt_frame_ctx*)> f(new rt_frame_ctx(), rt_frame_ctx_destroy);
+  f->n = n; f->band_rows = band_rows; f->dev.assign(n, 0);
+  rt_scene_info info;
+  for (int r = 0; r < n; r++) {
+    if (!scenes[r]) { rt_set_error("rt_frame_ctx_create: NULL scene"); return RT_ERR_ARG; }
+    rt_scene_info ir;
+    const int rc = rt_dscene_get_info(scenes[r], &ir, &f->dev[r]);
+    if (rc != RT_OK) return rc;
+    if (r == 0) info = ir;
+    else if (ir.width != info.width || ir.height != info.height) { rt_set_error("rt_frame_ctx_create: the scenes differ in size"); return RT_ERR_ARG; }
+    if (comms) {
+      if (!comms[r] || comms[r]->nranks != n || comms[r]->rank != r || comms[r]->device != f->dev[r]) {
+        rt_set_error("rt_frame_ctx_create: comms[r] must be rank r of n on the device of scenes[r]"); return RT_ERR_ARG;
+      }
+      f->comms.push_back(comms[r]);
+    }
+  }
+  f->W = info.width; f->H = info.height;
+  const int nb_max = rt_band_count(scenes[0], band_rows, 0, n);
+  f->tile_bytes = (size_t)nb_max * band_rows * f->W * 3; f->frame_bytes = (size_t)f->W * f->H * 3;
+  const bool exchange = !f->comms.empty();
+  f->slot.resize(slots);
+  for (auto& S : f->slot) {
+    S.ctx.assign(n, nullptr); S.stream.assign(n, nullptr); S.local.assign(exchange ? n : 0, nullptr);
+    for (int r = 0; r < n; r++) {
+      DeviceScope g(f->dev[r]);
+      const int rc = rt_dscene_fork(scenes[r], &S.ctx[r]);
+      if (rc != RT_OK) return rc;
+      if (hipStreamCreateWithFlags(&S.stream[r], hipStreamNonBlocking) != hipSuccess) { rt_set_error("rt_frame_ctx_create: stream creation failed"); return RT_ERR_DEVICE; }
+      if (exchange && hipMalloc((void**)&S.local[r], f->tile_bytes) != hipSuccess) { rt_set_error("rt_frame_ctx_create: tile allocation failed"); return RT_ERR_NOMEM; }
+    }
+    DeviceScope g(f->dev[0]);
+    if ((exchange && hipMalloc((void**)&S.gathered, f->tile_bytes * n) != hipSuccess) || hipMalloc((void**)&S.image, f->frame_bytes) != hipSuccess ||
+        hipHostMalloc((void**)&S.host, f->frame_bytes, hipHostMallocDefault) != hipSuccess) { rt_set_error("rt_frame_ctx_create: frame allocation failed"); return RT_ERR_NOMEM; }
+    if (hipEventCreate(&S.begin) != hipSuccess || hipEventCreate(&S.end) != hipSuccess) { rt_set_error("rt_frame_ctx_create: event creation failed"); return RT_ERR_DEVICE; }
+  }
+  *out = f.release();
+  return RT_OK;
+}
+
+extern "C" int rt_frame_enqueue(rt_frame_ctx* f, int slot, unsigned flags) {
+  if (!f || slot < 0 || slot >= (int)f->slot.size()) { rt_set_error("rt_frame_enqueue: bad argument"); return RT_ERR_ARG; }
+  rt_frame_ctx::Slot& S = f->slot[slot];
+  if (S.busy) { rt_set_error("rt_frame_enqueue: the slot's last frame has not been waited for"); return RT_ERR_ARG; }
+  const unsigned render_flags = flags & ~(unsigned)RT_RENDER_TIME;
+  { DeviceScope g(f->dev[0]); if (hipEventRecord(S.begin, S.stream[0]) != hipSuccess) { rt_set_error("rt_frame_enqueue: event record failed"); return RT_ERR_DEVICE; } }
+  int rc = RT_OK;
+  if (f->comms.empty()) {   // one device, no exchange: straight into the frame
+    rc = rt_render_rows(S.ctx[0], 0, f->H, S.image, nullptr, nullptr, S.stream[0], render_flags, nullptr);
+    if (rc != RT_OK) return rc;
+  } else {
+    for (int r = 0; r < f->n; r++) {
+      rc = rt_render_bands(S.ctx[r], f->band_rows, r, f->n, S.local[r], nullptr, nullptr, S.stream[r], render_flags, nullptr);
+      if (rc != RT_OK) return rc;
+    }
+    rc = rt_comm_group_begin();
+    if (rc != RT_OK) return rc;
+    for (int r = 0; r < f->n && rc == RT_OK; r++) rc = rt_gather_bands(f->comms[r], S.local[r], f->tile_bytes, S.gathered, S.stream[r]);
+    const int rc_end = rt_comm_group_end();
+    if (rc != RT_OK || rc_end != RT_OK) return rc != RT_OK ? rc : rc_end;
+    rc = rt_unpack_bands(S.gathered, f->tile_bytes, f->n, f->band_rows, f->W, f->H, 3, S.image, S.stream[0]);
+    if (rc != RT_OK) return rc;
+  }
+  DeviceScope g(f->dev[0]);
+  if (hipMemcpyAsync(S.host, S.image, f->frame_bytes, hipMemcpyDeviceToHost, S.stream[0]) != hipSuccess ||
+      hipEventRecord(S.end, S.stream[0]) != hipSuccess) { rt_set_error("rt_frame_enqueue: copy to the host failed"); return RT_ERR_DEVICE; }
+  S.busy = true;
+  return RT_OK;
+}
+
+extern "C" int rt_frame_wait(rt_frame_ctx* f, int slot, const uint8_t** h_rgb, float* frame_ms) {
+  if (!f || slot < 0 || slot >= (int)f->slot.size()) { rt_set_error("rt_frame_wait: bad argument"); return RT_ERR_ARG; }
+  rt_frame_ctx::Slot& S = f->slot[slot];
+  if (!S.busy) { rt_set_error("rt_frame_wait: nothing was enqueued in the slot"); return RT_ERR_ARG; }
+  DeviceScope g(f->dev[0]);
+  if (hipEventSynchronize(S.end) != hipSuccess) { rt_set_error("rt_frame_wait: the frame failed"); return RT_ERR_DEVICE; }
+  S.busy = false;
+  if (frame_ms) { float ms = 0.f; if (hipEventElapsedTime(&ms, S.begin, S.end) != hipSuccess) ms = 0.f; *frame_ms = ms; }
+  if (h_rgb) *h_rgb = S.host;
   return RT_OK;
 }

@@ -603,6 +603,8 @@ MaterialTable load_resources(const std::string& path) {   // parsing.cu:177-269
   return T;
 }
 
+void finish_scene(rt_scene& sc, int W, int H, int depth, double parse_seconds);
+
 void load_scene_into(rt_scene& sc, const std::string& scene_path, const std::string& res_path,
                      const std::string& base_dir, int W, int H, int depth) {
   const auto t_parse = Clock::now();
@@ -732,6 +734,8 @@ void load_scene_into(rt_scene& sc, const std::string& scene_path, const std::str
         const std::string path = (!tf->second.empty() && tf->second[0] == '/') ? tf->second : base_dir + tf->second;
         int tw = 0, th = 0; std::vector<uint8_t> rgb; std::string err;
         if (!rt_decode_image_file(path, tw, th, rgb, err)) throw Fail{err.rfind("No ", 0) == 0 ? RT_ERR_IO : RT_ERR_PARSE, err};
+        // (a texture names its texels by a 32-bit offset into the scene's one texel array)
+        if (sc.texels.size() + (size_t)tw * th >= (1ull << 32)) throw Fail{RT_ERR_LIMIT, "the textures of the scene hold more than 2^32 texels"};
         RtTexture t; t.first = (uint32_t)sc.texels.size(); t.width = (uint32_t)tw; t.height = (uint32_t)th; t.pad = 0;
         for (size_t q = 0; q < (size_t)tw * th; q++) sc.texels.push_back((uint32_t)rgb[3 * q] | ((uint32_t)rgb[3 * q + 1] << 8) | ((uint32_t)rgb[3 * q + 2] << 16));
         it = loaded.emplace(tname, (int)sc.textures.size()).first;
@@ -766,10 +770,17 @@ void load_scene_into(rt_scene& sc, const std::string& scene_path, const std::str
   c.top = top; c.bottom = -top; c.right = right; c.left = -right;
   c.scene_refr = scene_refr; c.width = W; c.height = H; c.max_depth = depth; c.shadows = shadows ? 1 : 0;
 
+  finish_scene(sc, W, H, depth, seconds_since(t_parse));
+}
+
+// What every way of making an rt_scene ends with, once camera, lights, materials, spheres, material lists and the triangle
+// arrays are in place: the octree over the triangles (main.cu:25-31), the flat records the kernels read, the summary.
+void finish_scene(rt_scene& sc, int W, int H, int depth, double parse_seconds) {
+  RtCamera& c = sc.cam;
   rt_scene_info& I = sc.info; memset(&I, 0, sizeof I);
-  I.parse_seconds = seconds_since(t_parse);
+  I.parse_seconds = parse_seconds;
   const auto t_build = Clock::now();
-  if (!mesh_mats.empty()) {
+  if (!sc.mesh_mat_first.empty()) {   // (the reference builds a tree whenever the scene has a mesh, main.cu:25)
     TreeBuilder tb(sc); tb.build();
     // Leaf-ordered copy of the intersection records: a leaf's triangles are one contiguous run, so the
     // traversal streams them without the index indirection.
@@ -938,6 +949,138 @@ extern "C" int rt_scene_load(const char* scene_json, const char* resources_json,
     delete sc; rt_set_error(e.what()); return RT_ERR_PARSE;
   }
   *out = sc;
+  return RT_OK;
+}
+
+// A scene from the caller's arrays: the same rt_scene as rt_scene_load makes of the files that describe it.
+extern "C" int rt_scene_create(const rt_scene_desc* D, rt_scene** out) {
+  if (!D || !out) { rt_set_error("rt_scene_create: NULL argument"); return RT_ERR_ARG; }
+  *out = nullptr;
+  const rt_camera_desc& C = D->camera;
+  if (C.width < 1 || C.height < 1 || C.width > 65535 || C.height > 65535) { rt_set_error("image size must be 1..65535 per side"); return RT_ERR_ARG; }
+  if (C.ray_depth < 0 || C.ray_depth >= RT_RAY_STACK) { rt_set_error("max ray depth must be 0..9"); return RT_ERR_LIMIT; }
+  if (D->n_lights < 0 || D->n_materials < 0 || D->n_mat_index < 0 || D->n_spheres < 0 || D->n_meshes < 0 || D->n_triangles < 0 ||
+      (D->n_lights && !D->lights) || (D->n_materials && !D->materials) || (D->n_mat_index && !D->mat_index) || (D->n_spheres && !D->spheres) ||
+      (D->n_meshes && (!D->mesh_mat_first || !D->mesh_mat_count)) || (D->n_triangles && (!D->tri_verts || !D->tri_normals || !D->tri_mesh))) {
+    rt_set_error("rt_scene_create: a count without its array, or a negative count"); return RT_ERR_ARG;
+  }
+  if (D->n_triangles && !D->n_meshes) { rt_set_error("rt_scene_create: triangles without a mesh"); return RT_ERR_ARG; }
+  auto list_ok = [&](int32_t first, int32_t count) { return first >= 0 && count >= 0 && (long long)first + count <= D->n_mat_index; };
+  for (int32_t i = 0; i < D->n_mat_index; i++)
+    if (D->mat_index[i] < 0 || D->mat_index[i] >= D->n_materials) { rt_set_error("rt_scene_create: material index out of range"); return RT_ERR_ARG; }
+  for (int32_t i = 0; i < D->n_spheres; i++)
+    if (!list_ok(D->spheres[i].mat_first, D->spheres[i].mat_count)) { rt_set_error("rt_scene_create: material list of a sphere out of range"); return RT_ERR_ARG; }
+  for (int32_t i = 0; i < D->n_meshes; i++)
+    if (!list_ok(D->mesh_mat_first[i], D->mesh_mat_count[i])) { rt_set_error("rt_scene_create: material list of a mesh out of range"); return RT_ERR_ARG; }
+  for (int32_t i = 0; i < D->n_triangles; i++)
+    if (D->tri_mesh[i] < 0 || D->tri_mesh[i] >= D->n_meshes) { rt_set_error("rt_scene_create: mesh index of a triangle out of range"); return RT_ERR_ARG; }
+  for (int32_t i = 0; i < D->n_materials; i++)
+    if (D->materials[i].type < RT_LAMBERT || D->materials[i].type > RT_DIELECTRIC) {
+      rt_set_error("rt_scene_create: material type must be 0..3 (the reference has no behaviour for TEXTURE; texture materials come in through rt_scene_load)");
+      return RT_ERR_ARG;
+    }
+  for (int32_t i = 0; i < D->n_lights; i++)
+    if (D->lights[i].type < RT_PUNCTUAL || D->lights[i].type > RT_DIRECTIONAL) { rt_set_error("rt_scene_create: light type must be 0..3"); return RT_ERR_ARG; }
+  rt_scene* sc = nullptr;
+  try {
+    const auto t0 = Clock::now();
+    sc = new rt_scene();
+    RtCamera& c = sc->cam; memset(&c, 0, sizeof c);
+    for (int k = 0; k < 3; k++) { c.u[k] = C.u[k]; c.v[k] = C.v[k]; c.w[k] = C.w[k]; c.pos[k] = C.pos[k]; c.bg[k] = C.bg_col[k]; }
+    c.left = C.left; c.right = C.right; c.bottom = C.bottom; c.top = C.top; c.scene_refr = C.scene_refr;
+    c.width = C.width; c.height = C.height; c.max_depth = C.ray_depth; c.shadows = C.shadows ? 1 : 0;
+    for (int32_t i = 0; i < D->n_lights; i++) {
+      const rt_light_desc& l = D->lights[i];
+      RtLight L; memset(&L, 0, sizeof L);
+      for (int k = 0; k < 3; k++) { L.col[k] = l.col[k]; L.pos[k] = l.pos[k]; L.dir[k] = l.dir[k]; }
+      L.type = l.type; L.angle = l.angle;
+      if (l.type == RT_SPOT) L.cos_half = cosf(l.angle / 2);   // lights.cu:289,343
+      sc->lights.push_back(L);
+    }
+    for (int32_t i = 0; i < D->n_materials; i++) {
+      const rt_material_desc& m = D->materials[i];
+      RtMaterial M; memset(&M, 0, sizeof M);
+      for (int k = 0; k < 3; k++) { M.col[k] = m.col[k]; M.att[k] = m.att[k]; }
+      M.param = m.param; M.type = m.type;
+      sc->materials.push_back(M);
+    }
+    sc->mat_index.assign(D->mat_index, D->mat_index + D->n_mat_index);
+    for (int32_t i = 0; i < D->n_spheres; i++) {
+      RtSphere S; memset(&S, 0, sizeof S);
+      for (int k = 0; k < 3; k++) S.c[k] = D->spheres[i].c[k];
+      S.r = D->spheres[i].r; S.mat_first = D->spheres[i].mat_first; S.mat_count = D->spheres[i].mat_count;
+      sc->spheres.push_back(S);
+    }
+    sc->mesh_mat_first.assign(D->mesh_mat_first, D->mesh_mat_first + D->n_meshes);
+    sc->mesh_mat_count.assign(D->mesh_mat_count, D->mesh_mat_count + D->n_meshes);
+    const size_t n = (size_t)D->n_triangles;
+    sc->tri_geom.resize(n); sc->tri_shade.resize(n);
+    sc->tri_verts.assign(D->tri_verts, D->tri_verts + 9 * n);
+    sc->tri_normals.assign(D->tri_normals, D->tri_normals + 9 * n);
+    if (D->tri_uv) sc->tri_uv.assign(D->tri_uv, D->tri_uv + 6 * n); else sc->tri_uv.assign(6 * n, 0.f);
+    for (size_t f = 0; f < n; f++) {   // mesh.cu:65-97, as the loader does for the faces of a file
+      RtTriGeom& g = sc->tri_geom[f]; RtTriShade& t = sc->tri_shade[f];
+      memset(&g, 0, sizeof g); memset(&t, 0, sizeof t);
+      const float* p = D->tri_verts + 9 * f; const float* nn = D->tri_normals + 9 * f;
+      for (int k = 0; k < 3; k++) {
+        g.v0[k] = p[k]; g.e1[k] = p[3 + k] - p[k]; g.e2[k] = p[6 + k] - p[k];
+        t.v1[k] = p[3 + k]; t.v2[k] = p[6 + k]; t.n0[k] = nn[k]; t.n1[k] = nn[3 + k]; t.n2[k] = nn[6 + k];
+      }
+      g.mesh = D->tri_mesh[f];
+    }
+    finish_scene(*sc, C.width, C.height, C.ray_depth, seconds_since(t0));
+  } catch (const Fail& f) {
+    delete sc; rt_set_error(f.msg); return f.code;
+  } catch (const std::bad_alloc&) {
+    delete sc; rt_set_error("out of host memory"); return RT_ERR_NOMEM;
+  } catch (const std::exception& e) {
+    delete sc; rt_set_error(e.what()); return RT_ERR_PARSE;
+  }
+  *out = sc;
+  return RT_OK;
+}
+
+extern "C" int rt_scene_describe(rt_scene* s, rt_scene_desc* out) {
+  if (!s || !out) { rt_set_error("rt_scene_describe: NULL argument"); return RT_ERR_ARG; }
+  if (!s->textures.empty()) { rt_set_error("rt_scene_describe: the scene has texture materials, which a description cannot carry"); return RT_ERR_LIMIT; }
+  try {
+    memset(out, 0, sizeof *out);
+    const RtCamera& c = s->cam; rt_camera_desc& C = out->camera;
+    for (int k = 0; k < 3; k++) { C.u[k] = c.u[k]; C.v[k] = c.v[k]; C.w[k] = c.w[k]; C.pos[k] = c.pos[k]; C.bg_col[k] = c.bg[k]; }
+    C.left = c.left; C.right = c.right; C.bottom = c.bottom; C.top = c.top; C.scene_refr = c.scene_refr;
+    C.width = c.width; C.height = c.height; C.ray_depth = c.max_depth; C.shadows = c.shadows;
+    s->desc_lights.clear(); s->desc_materials.clear(); s->desc_spheres.clear(); s->desc_tri_mesh.clear();
+    for (const RtLight& L : s->lights) {
+      rt_light_desc l; memset(&l, 0, sizeof l);
+      for (int k = 0; k < 3; k++) { l.col[k] = L.col[k]; l.pos[k] = L.pos[k]; l.dir[k] = L.dir[k]; }
+      l.angle = L.angle; l.type = L.type;
+      s->desc_lights.push_back(l);
+    }
+    for (const RtMaterial& M : s->materials) {
+      rt_material_desc m; memset(&m, 0, sizeof m);
+      // (a texture material that no object of the scene uses - s->textures is empty - is described as its plain counterpart: nothing reads it)
+      for (int k = 0; k < 3; k++) { m.col[k] = M.col[k]; m.att[k] = M.type >= RT_TEX_LAMBERT ? 0.f : M.att[k]; }
+      m.param = M.param; m.type = M.type >= RT_TEX_LAMBERT ? M.type - RT_TEX_LAMBERT : M.type;
+      s->desc_materials.push_back(m);
+    }
+    for (const RtSphere& S : s->spheres) {
+      rt_sphere_desc d; memset(&d, 0, sizeof d);
+      for (int k = 0; k < 3; k++) d.c[k] = S.c[k];
+      d.r = S.r; d.mat_first = S.mat_first; d.mat_count = S.mat_count;
+      s->desc_spheres.push_back(d);
+    }
+    for (const RtTriGeom& g : s->tri_geom) s->desc_tri_mesh.push_back(g.mesh);
+  } catch (const std::bad_alloc&) {
+    rt_set_error("out of host memory"); return RT_ERR_NOMEM;
+  }
+  out->n_lights = (int32_t)s->desc_lights.size(); out->lights = s->desc_lights.data();
+  out->n_materials = (int32_t)s->desc_materials.size(); out->materials = s->desc_materials.data();
+  out->n_mat_index = (int32_t)s->mat_index.size(); out->mat_index = s->mat_index.data();
+  out->n_spheres = (int32_t)s->desc_spheres.size(); out->spheres = s->desc_spheres.data();
+  out->n_meshes = (int32_t)s->mesh_mat_first.size(); out->mesh_mat_first = s->mesh_mat_first.data(); out->mesh_mat_count = s->mesh_mat_count.data();
+  out->n_triangles = (int32_t)s->tri_geom.size();
+  out->tri_verts = s->tri_verts.data(); out->tri_normals = s->tri_normals.data(); out->tri_uv = s->tri_uv.empty() ? nullptr : s->tri_uv.data();
+  out->tri_mesh = s->desc_tri_mesh.data();
   return RT_OK;
 }
 

@@ -8,6 +8,8 @@
 #include <cstdint>
 #include <cstdio>
 #include <cstring>
+#include <new>
+#include <stdexcept>
 #include <string>
 #include <vector>
 
@@ -225,6 +227,7 @@ bool decode_jpeg(const std::vector<uint8_t>& d, int& W, int& H, std::vector<uint
       H = (int)be16(&s[1]); W = (int)be16(&s[3]);
       const int nc = s[5];
       if ((nc != 1 && nc != 3) || n < 6 + 3 * (size_t)nc || W <= 0 || H <= 0) { err = "JPEG with other than one or three components"; return false; }
+      if (W > 16384 || H > 16384) { err = "JPEG larger than 16384 pixels a side"; return false; }
       comps.assign(nc, Component());
       for (int c = 0; c < nc; c++) {
         comps[c].id = s[6 + 3 * c]; comps[c].h = s[7 + 3 * c] >> 4; comps[c].v = s[7 + 3 * c] & 15; comps[c].tq = s[8 + 3 * c];
@@ -237,6 +240,7 @@ bool decode_jpeg(const std::vector<uint8_t>& d, int& W, int& H, std::vector<uint
     else if (m == 0xee && n >= 12 && !memcmp(s, "Adobe", 5)) adobe_transform = s[11];
     else if (m == 0xda) {   // scan: the entropy-coded data follows the header
       if (!have_frame) { err = "JPEG scan before its frame header"; return false; }
+      if (n < 1) { err = "JPEG scan header cut short"; return false; }
       const int ns = s[0];
       if (ns != (int)comps.size() || n < 1 + 2 * (size_t)ns + 3) { err = "JPEG with several scans not supported"; return false; }
       for (int k = 0; k < ns; k++) {
@@ -254,7 +258,7 @@ bool decode_jpeg(const std::vector<uint8_t>& d, int& W, int& H, std::vector<uint
         c.bw = mcux * c.h; c.bh = mcuy * c.v; c.stride = (size_t)c.bw * 8;
         c.plane.assign(c.stride * (size_t)c.bh * 8, 0); c.pred = 0;
       }
-      BitReader br{&d[at + 2 + len], d.data() + d.size()};
+      BitReader br{d.data() + std::min(at + 2 + len, d.size()), d.data() + d.size()};   // (a scan header that ends the file: no data, zeros are fed)
       int until_restart = restart_interval;
       for (int my = 0; my < mcuy; my++)
         for (int mx = 0; mx < mcux; mx++) {
@@ -331,12 +335,20 @@ bool rt_decode_image_file(const std::string& path, int& W, int& H, std::vector<u
 
 extern "C" int rt_image_load(const char* path, int* width, int* height, uint8_t* rgb, size_t capacity) {
   if (!path || !width || !height) { rt_set_error("rt_image_load: NULL argument"); return RT_ERR_ARG; }
-  int W = 0, H = 0; std::vector<uint8_t> px; std::string err;
-  if (!rt_decode_image_file(path, W, H, px, err)) { rt_set_error(err); return err.rfind("No ", 0) == 0 ? RT_ERR_IO : RT_ERR_PARSE; }
-  *width = W; *height = H;
-  if (rgb) {
-    if (capacity < px.size()) { rt_set_error("rt_image_load: the buffer is smaller than width * height * 3"); return RT_ERR_ARG; }
-    memcpy(rgb, px.data(), px.size());
+  try {   // (no exception leaves an extern "C" function: a decode that runs out of memory is an error code)
+    int W = 0, H = 0; std::vector<uint8_t> px; std::string err;
+    if (!rt_decode_image_file(path, W, H, px, err)) { rt_set_error(err); return err.rfind("No ", 0) == 0 ? RT_ERR_IO : RT_ERR_PARSE; }
+    *width = W; *height = H;
+    if (rgb) {
+      if (capacity < px.size()) { rt_set_error("rt_image_load: the buffer is smaller than width * height * 3"); return RT_ERR_ARG; }
+      memcpy(rgb, px.data(), px.size());
+    }
+    return RT_OK;
+  } catch (const std::bad_alloc&) {
+    rt_set_error("rt_image_load: out of memory");
+    return RT_ERR_NOMEM;
+  } catch (const std::exception& e) {
+    rt_set_error(std::string("rt_image_load: ") + e.what());
+    return RT_ERR_PARSE;
   }
-  return RT_OK;
 }

@@ -115,6 +115,11 @@ struct rt_scene {
   rt_scene_info info;
   int32_t max_pushes_per_hit = 0;                 // most rays one hit can push: 1 per reflective, 2 per dielectric material of a primitive
   int32_t dielectric_mesh = 0;                    // some mesh carries a dielectric material
+  // the arrays behind rt_scene_describe (filled on request)
+  std::vector<rt_light_desc> desc_lights;
+  std::vector<rt_material_desc> desc_materials;
+  std::vector<rt_sphere_desc> desc_spheres;
+  std::vector<int32_t> desc_tri_mesh;
 };
 
 void rt_set_error(const std::string& msg);

@@ -237,6 +237,11 @@ __global__ __launch_bounds__(RT_BLOCK) void render_tiles(const RtDeviceView S, c
 
 }  // namespace
 
+int rt_preload_lane_kernels() {
+  hipFuncAttributes attr;   // asking for a kernel's attributes makes the runtime load the code object it is in
+  return (int)hipFuncGetAttributes(&attr, reinterpret_cast<const void*>(&render_tiles<false, false>));
+}
+
 void rt_launch_lane_kernel(const RtDeviceView& view, const RowMap& rows, bool bounce, bool count, uint8_t* rgb, int32_t* ids,
                            float* ts, unsigned long long* counters, bool tally, hipStream_t stream) {
   const dim3 grid((view.cam.width + RT_TILE_W - 1) / RT_TILE_W, (rows.n_local + RT_TILE_H - 1) / RT_TILE_H), block(RT_BLOCK);

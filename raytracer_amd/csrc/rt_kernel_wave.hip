@@ -1557,7 +1557,18 @@ __global__ __launch_bounds__(RT_WBLOCK, (BOUNCE && !QPRIMARY) ? RT_WAVES_PER_SIM
 
 int rt_preload_wave_kernels() {
   hipFuncAttributes attr;   // asking for a kernel's attributes makes the runtime load the code object it is in
-  return (int)hipFuncGetAttributes(&attr, reinterpret_cast<const void*>(&render_wave<false, false, false, true>));
+  // (one code object holds every variant; the variants a frame of any kind launches are all asked for, so that none of them
+  //  is looked up for the first time inside a render call)
+  const void* const kernels[] = {
+      reinterpret_cast<const void*>(&render_wave<false, false, false, true>), reinterpret_cast<const void*>(&render_wave<false, false, false>),
+      reinterpret_cast<const void*>(&render_wave<false, true, false>), reinterpret_cast<const void*>(&render_wave<true, false, false>),
+      reinterpret_cast<const void*>(&render_wave<true, true, false>), reinterpret_cast<const void*>(&render_wave<true, false, true>),
+      reinterpret_cast<const void*>(&render_wave<true, true, true>), reinterpret_cast<const void*>(&render_wave<true, false, true, false, false, true>),
+      reinterpret_cast<const void*>(&render_wave<true, true, true, false, false, true>), reinterpret_cast<const void*>(&render_wave<false, false, false, false, true>),
+      reinterpret_cast<const void*>(&render_wave<false, true, false, false, true>), reinterpret_cast<const void*>(&render_wave<true, false, false, false, true>),
+      reinterpret_cast<const void*>(&render_wave<true, true, false, false, true>)};
+  for (const void* k : kernels) { const hipError_t e = hipFuncGetAttributes(&attr, k); if (e != hipSuccess) return (int)e; }
+  return (int)hipSuccess;
 }
 
 void rt_launch_wave_kernel(const RtDeviceView& V, const RowMap& rows, bool bounce, bool count, uint8_t* rgb, int32_t* ids,

@@ -226,8 +226,12 @@ void rt_launch_lane_kernel(const RtDeviceView& view, const RowMap& rows, bool bo
                            float* ts, unsigned long long* counters, bool tally, hipStream_t stream);
 // wf.enabled: bounce rays go to wf.out and terms to the term list instead of the in-kernel stack; wf.in != nullptr: the
 // launch renders the rays of that queue instead of primary rays (rows, rgb, ids, ts unused).
-// Loads the code object of the wave kernels on the current device (returns a hipError_t as int).
+// Each loads the code object of its source file's kernels on the current device (returns a hipError_t as int): the HIP
+// runtime loads a code object when one of its kernels is first asked for, and a caller that must not allocate inside a
+// render call (rt_render_rows_static) wants that behind it.
 int rt_preload_wave_kernels();
+int rt_preload_lane_kernels();
+int rt_preload_queue_kernels();
 void rt_launch_wave_kernel(const RtDeviceView& view, const RowMap& rows, bool bounce, bool count, uint8_t* rgb, int32_t* ids,
                            float* ts, unsigned long long* counters, bool tally, const RtQueues& wf, hipStream_t stream);
 // Coherence order of a queue's rays (any order gives the same image; waves of rays that start close together and head

@@ -249,6 +249,13 @@ void rt_launch_ray_order(const RtQRay* rays, RtQState* state, uint32_t in_index,
   hipLaunchKernelGGL(q_scatter, dim3(QGRID), dim3(QBLOCK), 0, stream, (const RtQState*)state, in_index, queue_cap, keys, bins, order);
 }
 
+int rt_preload_queue_kernels() {
+  hipFuncAttributes attr;   // asking for a kernel's attributes makes the runtime load the code object it is in
+  hipError_t e = hipFuncGetAttributes(&attr, reinterpret_cast<const void*>(&q_advance));
+  if (e == hipSuccess) e = hipFuncGetAttributes(&attr, reinterpret_cast<const void*>(&q_resolve));
+  return (int)e;
+}
+
 void rt_launch_queue_advance(RtQState* state, uint32_t clear_index, hipStream_t stream) {
   hipLaunchKernelGGL(q_advance, dim3(1), dim3(1), 0, stream, state, clear_index);
 }

@@ -9,7 +9,9 @@
 //   --device N      HIP device of a single-GPU render (default 0)
 //   --gpus N        render the frame on devices 0..N-1 of this node: 16-row bands dealt round-robin, one RCCL gather
 //   --stats         one JSON line: ray counts, time per phase (parse, octree, upload, kernel, copy, png), Mrays/s and the
-//                   fraction of the FP32 vector roofline (from one more, instrumented, launch outside the timed part)
+//                   algorithmic fraction of the FP32 vector roofline (from one more, instrumented, launch outside the timed part)
+//   --counters F    with --stats: a hardware-counter record of this very frame (profiles/r*_counters.json); the FP32
+//                   arithmetic the vector units executed is then printed beside the algorithmic figure
 //   --dump-ids F    primary-hit primitive ids, W*H little-endian int32 in row order (triangle >= 0, sphere s = -2-s, miss = -1)
 #include <chrono>
 #include <cstdio>
@@ -52,6 +54,8 @@ int main(int ac, char** av) {
   if (option_value(ac, av, "--gpus")) gpus = atoi(option_value(ac, av, "--gpus"));
   const bool want_stats = has_option(ac, av, "--stats");
   const char* ids_path = option_value(ac, av, "--dump-ids");
+  const char* counters_path = option_value(ac, av, "--counters");
+  const char* scene_path = option_value(ac, av, "-s");
   printf("%s", banner.c_str());
   if (gpus < 0 || gpus > 64) { fprintf(stderr, "run: --gpus must be 1..64\n"); return 1; }
   if (gpus > 0 && ids_path) { fprintf(stderr, "run: --dump-ids is a single-GPU option\n"); return 1; }
@@ -120,12 +124,35 @@ int main(int ac, char** av) {
     // quadratic 20, shading 150 per ray), over the kernel time, against the 157.3 TFLOP/s FP32 vector peak of an MI355X
     const double flop = 24.0 * counted.node_tests + 61.0 * counted.tri_tests + 20.0 * counted.sphere_tests + 150.0 * counted.rays;
     const double tflops = st.kernel_ms > 0 ? flop / (st.kernel_ms * 1e-3) / 1e12 : 0.0;
-    printf("{\"rays\": %llu, \"shadow_rays\": %llu, \"gpus\": %d, \"parse_ms\": %.3f, \"octree_ms\": %.3f, \"upload_ms\": %.3f, "
+    // `algorithmic_frac` prices the tests the REFERENCE makes for this frame; the kernels prove most of them away without
+    // executing them.  What the vector units executed can only be read from hardware counters: --counters FILE names a
+    // counter record as tools/profile_to_json.py writes them (profiles/r*_counters.json), and when its workload is this
+    // very frame its executed FLOP are printed beside the algorithmic figure.
+    double executed_tflops = -1.0;
+    if (counters_path) {
+      std::string text;
+      if (FILE* f = fopen(counters_path, "rb")) { char buf[4096]; size_t k; while ((k = fread(buf, 1, sizeof buf, f)) > 0) text.append(buf, k); fclose(f); }
+      std::string base = scene_path ? scene_path : "";
+      const size_t slash = base.rfind('/');
+      if (slash != std::string::npos) base = base.substr(slash + 1);
+      char want[512];
+      snprintf(want, sizeof want, "\"workload\": \"scenes/%s %dx%d depth %d\"", base.c_str(), W, H, depth);
+      const size_t at = text.find("\"executed_fp32_flop_per_launch\":");
+      if (text.find(want) != std::string::npos && at != std::string::npos && st.kernel_ms > 0)
+        executed_tflops = strtod(text.c_str() + at + 33, nullptr) / (st.kernel_ms * 1e-3) / 1e12;
+    }
+    printf("{\"rays\": %llu, \"shadow_rays\": %llu, \"rays_walked\": %llu, \"gpus\": %d, \"parse_ms\": %.3f, \"octree_ms\": %.3f, \"upload_ms\": %.3f, "
            "\"kernel_ms\": %.3f, \"copy_ms\": %.3f, \"png_ms\": %.3f, \"mrays_per_s\": %.2f, \"node_tests\": %llu, \"tri_tests\": %llu, "
-           "\"algorithmic_tflops\": %.2f, \"fp32_roofline_frac\": %.4f, \"version\": \"%s\"}\n",
-           (unsigned long long)st.rays, (unsigned long long)st.shadow_rays, n_dev, info.parse_seconds * 1e3, info.build_seconds * 1e3,
+           "\"algorithmic_tflops\": %.2f, \"algorithmic_frac\": %.4f, "
+           "\"algorithmic_frac_is\": \"FLOP of the tests and shading the reference performs for this frame over kernel time and the 157.3 TFLOP/s FP32 peak: work delivered, not work executed\", ",
+           (unsigned long long)st.rays, (unsigned long long)st.shadow_rays, (unsigned long long)st.rays_traced, n_dev, info.parse_seconds * 1e3, info.build_seconds * 1e3,
            upload_s * 1e3, st.kernel_ms, st.copy_ms, png_s * 1e3, st.kernel_ms > 0 ? st.rays / (st.kernel_ms * 1e3) : 0.0,
-           (unsigned long long)counted.node_tests, (unsigned long long)counted.tri_tests, tflops, tflops / (157.3 * n_dev), rt_version());
+           (unsigned long long)counted.node_tests, (unsigned long long)counted.tri_tests, tflops, tflops / (157.3 * n_dev));
+    if (executed_tflops >= 0.0)
+      printf("\"executed_tflops\": %.2f, \"executed_frac\": %.4f, \"executed_frac_of_fma_free_peak\": %.4f, ", executed_tflops, executed_tflops / (157.3 * n_dev),
+             executed_tflops / (78.65 * n_dev));
+    else printf("\"executed_tflops\": null, ");
+    printf("\"version\": \"%s\"}\n", rt_version());
   }
   return status;
 }

@@ -49,7 +49,7 @@ def test_cli_gpus_stats_and_dump_ids(tmp_path):
     assert many.returncode == 0, many.stdout
     assert np.array_equal(np.array(Image.open(a)), np.array(Image.open(b)))
     s1, s2 = json.loads(one.stdout.strip().splitlines()[-1]), json.loads(many.stdout.strip().splitlines()[-1])
-    for key in ("parse_ms", "octree_ms", "upload_ms", "kernel_ms", "copy_ms", "png_ms", "mrays_per_s", "fp32_roofline_frac"):
+    for key in ("parse_ms", "octree_ms", "upload_ms", "kernel_ms", "copy_ms", "png_ms", "mrays_per_s", "algorithmic_frac", "rays_walked"):
         assert key in s1 and key in s2
     assert s1["rays"] == s2["rays"] > 200 * 150 and s1["kernel_ms"] > 0 and s2["gpus"] == 1
     _, want_ids, _, _ = rt.DeviceScene(rt.Scene("scenes/meshMedBunny.json", 200, 150, 3)).render_host()
