@@ -34,6 +34,7 @@ ABI_SYMBOLS = (
     "rt_host_alloc", "rt_host_free", "rt_band_count", "rt_render_bands", "rt_dscene_get_info",
     "rt_comm_unique_id", "rt_comm_init_rank", "rt_comm_init_all", "rt_comm_destroy", "rt_comm_group_begin", "rt_comm_group_end",
     "rt_gather_bands", "rt_unpack_bands", "rt_render_frame_gathered",
+    "rt_frame_ctx_create", "rt_frame_ctx_destroy", "rt_frame_enqueue", "rt_frame_wait",
     "rt_write_png", "rt_image_load", "rt_strerror", "rt_last_error", "rt_version",
 )
 
@@ -158,6 +159,11 @@ def lib():
         L.rt_unpack_bands.argtypes = [C.c_void_p, C.c_size_t, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]
         L.rt_render_frame_gathered.argtypes = [C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.c_int, C.c_int, C.c_void_p, C.c_uint,
                                                C.POINTER(Stats)]
+        L.rt_frame_ctx_create.argtypes = [C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.c_int, C.c_int, C.c_int, C.POINTER(C.c_void_p)]
+        L.rt_frame_ctx_destroy.argtypes = [C.c_void_p]
+        L.rt_frame_ctx_destroy.restype = None
+        L.rt_frame_enqueue.argtypes = [C.c_void_p, C.c_int, C.c_uint]
+        L.rt_frame_wait.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_void_p), C.POINTER(C.c_float)]
         L.rt_write_png.argtypes = [C.c_char_p, C.c_int, C.c_int, C.c_void_p]
         L.rt_image_load.argtypes = [C.c_char_p, C.POINTER(C.c_int), C.POINTER(C.c_int), C.c_void_p, C.c_size_t]
         L.rt_strerror.argtypes = [C.c_int]
@@ -382,6 +388,37 @@ def render_frame_gathered(dscenes, comms, band_rows=16, flags=0):
     _check(lib().rt_render_frame_gathered((C.c_void_p * n)(*[d.h.value for d in dscenes]), (C.c_void_p * n)(*[c.h.value for c in comms]),
                                           n, band_rows, rgb.ctypes.data, flags, C.byref(st)))
     return rgb, st.as_dict()
+
+
+class FramePipeline:
+    """rt_frame_ctx: frames in flight on the devices of one process; everything is allocated here, nothing per frame."""
+
+    def __init__(self, dscenes, comms=None, band_rows=16, slots=2):
+        n = len(dscenes)
+        self.h = C.c_void_p()
+        self.width, self.height, self.slots = dscenes[0].width, dscenes[0].height, slots
+        self._keep = (dscenes, comms)
+        cs = (C.c_void_p * n)(*[c.h.value for c in comms]) if comms else None
+        _check(lib().rt_frame_ctx_create((C.c_void_p * n)(*[d.h.value for d in dscenes]), cs, n, band_rows, slots, C.byref(self.h)))
+
+    def enqueue(self, slot, flags=0):
+        _check(lib().rt_frame_enqueue(self.h, slot, flags))
+
+    def wait(self, slot, copy=True):
+        """The slot's frame as an (H, W, 3) uint8 array (a copy unless copy=False: then a view of the slot's page-locked
+        buffer, valid until the slot is enqueued again) and its first-launch-to-host time in ms."""
+        p, ms = C.c_void_p(), C.c_float()
+        _check(lib().rt_frame_wait(self.h, slot, C.byref(p), C.byref(ms)))
+        buf = (C.c_ubyte * (self.width * self.height * 3)).from_address(p.value)
+        a = np.frombuffer(buf, np.uint8).reshape(self.height, self.width, 3)
+        return (a.copy() if copy else a), ms.value
+
+    def close(self):
+        if getattr(self, "h", None):
+            lib().rt_frame_ctx_destroy(self.h)
+            self.h = None
+
+    __del__ = close
 
 
 def band_rows_of(height, band_rows, rank, nranks):

@@ -12,6 +12,8 @@
 //                   algorithmic fraction of the FP32 vector roofline (from one more, instrumented, launch outside the timed part)
 //   --counters F    with --stats: a hardware-counter record of this very frame (profiles/r*_counters.json); the FP32
 //                   arithmetic the vector units executed is then printed beside the algorithmic figure
+//   --frames K      after the image: the same frame K more times through a pipeline set up once (rt_frame_ctx): with --stats the
+//                   mean time of a frame rendered alone (first launch to host memory) and the time per frame with frames in flight
 //   --dump-ids F    primary-hit primitive ids, W*H little-endian int32 in row order (triangle >= 0, sphere s = -2-s, miss = -1)
 #include <chrono>
 #include <cstdio>
@@ -52,6 +54,8 @@ int main(int ac, char** av) {
   if (option_value(ac, av, "-i")) img = option_value(ac, av, "-i"); else banner += "+ Image: image.png\n";
   if (option_value(ac, av, "--device")) device = atoi(option_value(ac, av, "--device"));
   if (option_value(ac, av, "--gpus")) gpus = atoi(option_value(ac, av, "--gpus"));
+  const int frames = option_value(ac, av, "--frames") ? atoi(option_value(ac, av, "--frames")) : 0;
+  if (frames < 0 || frames > 100000) { fprintf(stderr, "run: --frames must be 0..100000\n"); return 1; }
   const bool want_stats = has_option(ac, av, "--stats");
   const char* ids_path = option_value(ac, av, "--dump-ids");
   const char* counters_path = option_value(ac, av, "--counters");
@@ -101,6 +105,36 @@ int main(int ac, char** av) {
   const bool rendered = rc == RT_OK;
   if (!rendered) printf("kernel launch failed with error \"%s\".\n", rt_last_error());   // main.cu:51-54: report, carry on
   int status = 0;
+  // --frames K: the same frame K more times through a pipeline that is set up once (rt_frame_ctx), first one frame at a
+  // time (latency: first launch to the frame in host memory), then with frames in flight (throughput)
+  double frame_latency_ms = 0.0, pipelined_ms = 0.0; int in_flight = 0; bool frames_equal = true;
+  if (frames > 0 && rendered) {
+    in_flight = frames < 3 ? frames : (n_dev >= 6 ? 3 : (n_dev > 1 ? 2 : 3));
+    rt_frame_ctx* fc = nullptr;
+    rc = rt_frame_ctx_create(ds.data(), gpus > 0 ? comms.data() : nullptr, n_dev, 16, in_flight, &fc);
+    if (rc != RT_OK) { fprintf(stderr, "run: %s\n", rt_last_error()); status = 1; }
+    else {
+      const uint8_t* got = nullptr; float ms = 0.f; bool ok = true;
+      for (int s = 0; s < in_flight && ok; s++) ok = rt_frame_enqueue(fc, s, 0) == RT_OK && rt_frame_wait(fc, s, &got, &ms) == RT_OK;   // every slot once: streams, RCCL channels
+      double sum = 0.0;
+      for (int k = 0; k < frames && ok; k++) {
+        ok = rt_frame_enqueue(fc, 0, 0) == RT_OK && rt_frame_wait(fc, 0, &got, &ms) == RT_OK;
+        sum += ms;
+        if (ok && memcmp(got, rgb, px * 3) != 0) frames_equal = false;
+      }
+      frame_latency_ms = sum / frames;
+      const auto tp = clk::now();
+      for (int k = 0; k < frames + in_flight && ok; k++) {
+        const int s = k % in_flight;
+        if (k >= in_flight) { ok = rt_frame_wait(fc, s, &got, nullptr) == RT_OK; if (ok && memcmp(got, rgb, px * 3) != 0) frames_equal = false; }
+        if (k < frames && ok) ok = rt_frame_enqueue(fc, s, in_flight > 1 ? RT_RENDER_STRIPS : 0) == RT_OK;
+      }
+      pipelined_ms = seconds_since(tp) * 1e3 / frames;
+      if (!ok) { fprintf(stderr, "run: %s\n", rt_last_error()); status = 1; }
+      if (!frames_equal) { fprintf(stderr, "run: a frame of the pipeline differs from the first frame\n"); status = 1; }
+      rt_frame_ctx_destroy(fc);
+    }
+  }
   const auto t_png = clk::now();
   rc = rt_write_png(img.c_str(), W, H, rgb);
   if (rc != RT_OK) { fprintf(stderr, "run: %s\n", rt_last_error()); status = 1; }
@@ -152,6 +186,8 @@ int main(int ac, char** av) {
       printf("\"executed_tflops\": %.2f, \"executed_frac\": %.4f, \"executed_frac_of_fma_free_peak\": %.4f, ", executed_tflops, executed_tflops / (157.3 * n_dev),
              executed_tflops / (78.65 * n_dev));
     else printf("\"executed_tflops\": null, ");
+    if (frames > 0) printf("\"frames\": %d, \"frame_latency_ms\": %.4f, \"frames_in_flight\": %d, \"pipelined_ms_per_frame\": %.4f, \"frames_identical\": %s, ", frames,
+                           frame_latency_ms, in_flight, pipelined_ms, frames_equal ? "true" : "false");
     printf("\"version\": \"%s\"}\n", rt_version());
   }
   return status;

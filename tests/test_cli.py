@@ -56,6 +56,20 @@ def test_cli_gpus_stats_and_dump_ids(tmp_path):
     assert np.array_equal(np.fromfile(ids, np.int32).reshape(150, 200), want_ids)
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("extra", [[], ["--gpus", "1"]])
+def test_cli_frames_in_flight(tmp_path, extra):
+    # --frames K: the pipeline set up once (rt_frame_ctx) renders the frame K times alone and K times with frames in flight;
+    # every one of them must be the image that was written, and --stats carries both times
+    import json
+    out = subprocess.run([RUN, "-s", "scenes/meshMedBunny.json", "-w", "320", "-h", "200", "-i", str(tmp_path / "f.png"), "--stats", "--frames", "6"] + extra,
+                         cwd=rt.ASSETS, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=120)
+    assert out.returncode == 0, out.stdout + out.stderr
+    st = json.loads(out.stdout.strip().splitlines()[-1])
+    assert st["frames"] == 6 and st["frames_identical"] is True and st["frame_latency_ms"] > 0 and st["pipelined_ms_per_frame"] > 0
+    assert st["frames_in_flight"] == 3
+
+
 def test_cli_reports_an_unwritable_image(tmp_path):
     # without a GPU the upload fails first (status 1, no CPU fallback); the status is never 0 when no image was written
     out = subprocess.run([RUN, "-s", "scenes/sphere.json", "-i", str(tmp_path / "no_such_dir" / "x.png")], cwd=rt.ASSETS,
