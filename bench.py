@@ -98,6 +98,13 @@ def main():
     sys.stdout.flush()
     real_stdout = os.dup(1)
     os.dup2(2, 1)
+    # A rank of six or more GPUs keeps four short frames in flight (below); with the collective's stream that is more streams than
+    # the four hardware queues a process gets by default, and streams that share a queue run one after the other.  Eight queues
+    # for such a process (measured on one GPU with the bands of one rank of 8: 0.223 -> 0.201 ms per frame); it has to be in the
+    # environment before the HIP runtime starts.
+    parts = max(int(os.environ.get("WORLD_SIZE", "1")), int(os.environ.get("RT_BENCH_SHARE_OF", "0") or 0))
+    if parts >= 6 and int(os.environ.get("GPU_MAX_HW_QUEUES", "4") or 4) < 8 and os.environ.get("RT_BENCH_KEEP_QUEUES") != "1":
+        os.environ["GPU_MAX_HW_QUEUES"] = "8"
     import torch
     import torch.distributed as dist
     import raytracer_amd as rt
@@ -138,9 +145,12 @@ def main():
         dist.init_process_group("nccl", device_id=dev)
     # Two or three frame tiles per rank: the gather of frame k runs on the collective's stream while frame k+1 is rendered.
     two_deep = dist_on and os.environ.get("RT_BENCH_ONE_STREAM") != "1"
-    # (three frames in flight from six GPUs on: a share of an eighth of the frame is so short that two of them still end on
-    #  their long waves - 0.45 -> 0.39 ms per frame for the bands of one GPU of 8; no gain for one of 4 or 2, a loss with four)
-    in_flight = max(2, int(os.environ.get("RT_BENCH_IN_FLIGHT", "3" if part_world >= 6 else "2"))) if two_deep else 1
+    # (A rank's launch lasts as long as its longest wave, a silhouette tile's 0.5 ms, however small its share: what a rank
+    #  renders per unit of time is the number of frames in flight over that.  Measured on one GPU with the bands of one rank
+    #  (tools/exp_in_flight.sh, tools/exp_share_launch_only.py): of 8, 0.31 / 0.22 / 0.20 ms per frame with two / three / four in
+    #  flight (four need the eight hardware queues above; the launches alone, without an exchange, take 0.28 / 0.21 / 0.17); of 4,
+    #  0.36 / 0.335 with two / three, no gain beyond; of 2, two frames already reach the single-GPU rate.)
+    in_flight = max(2, int(os.environ.get("RT_BENCH_IN_FLIGHT", "4" if part_world >= 6 else ("3" if part_world >= 4 else "2")))) if two_deep else 1
     local = [torch.zeros((nb_max * BAND_ROWS, W, 3), dtype=torch.uint8, device=dev) for _ in range(max(in_flight, 2) if dist_on else 1)]
     gathered = [[torch.zeros_like(local[0]) for _ in range(world)] for _ in local] if (dist_on and rank == 0) else None
     pending = [None] * len(local)

@@ -141,6 +141,9 @@ __device__ __forceinline__ bool wave_bundle(uint64_t cls, const RtVec3& e, const
 // rays in `live` (wave_bundle): on entering a leaf the walk leaves out the triangles that no ray of the bundle can be
 // accepted by.  cull == 0, or the variant of the block without that code (!CULL: kernels whose rays never form a
 // bundle): every triangle of every leaf entered is tested.
+#ifdef RT_WAVE_TIMES_CLK
+__device__ float* rt_dbg_ts();   // the `t` output of the launch (defined behind the kernel's argument block)
+#endif
 template <bool CULL>
 __device__ __forceinline__ uint64_t walk_asm(const float4* nodes, uint32_t variant, uint32_t zpat, const float4* tri_leaf, uint32_t top_first, uint32_t rem,
                                              uint64_t live, const RtVec3& e, const RtVec3& d, const RtVec3& inv, const RtVec3& fc, float neg_eb,
@@ -157,6 +160,9 @@ __device__ __forceinline__ uint64_t walk_asm(const float4* nodes, uint32_t varia
   const uint64_t a_nodes = (uint64_t)(uintptr_t)nodes, a_tri = (uint64_t)(uintptr_t)tri_leaf;
   const float cmax = rt_max3(fabsf(fc.x), fabsf(fc.y), fabsf(fc.z));
   float a_det = 0.f, a_nb = 0.f, a_ng = 0.f, a_nt = 0.f;
+#ifdef RT_WAVE_TIMES_CLK
+  uint32_t dbg_n1 = 0u, dbg_n2 = 0u; unsigned long long dbg_out = 0ull;
+#endif
 #ifdef RT_WALK_PRIO
   uint32_t a_work = uni(rt_walk_work);   // measurement builds: leaves entered by the wave so far, over all its walks (see RT_PRIO_STEP in rt_trace_asm.inc)
 #define RT_PRIO_OPERAND , "+{s23}"(a_work)
@@ -197,6 +203,10 @@ __device__ __forceinline__ uint64_t walk_asm(const float4* nodes, uint32_t varia
             "v75", "v76", "v77", "v78", "v79", "vcc", "scc");
     }
     if (a_res == 0u) break;
+#ifdef RT_WAVE_TIMES_CLK
+    const unsigned long long dbg_t0 = __builtin_amdgcn_s_memtime();
+    if (a_res == 1u) dbg_n1++; else dbg_n2++;
+#endif
     if (a_res == 1u) {
       // the exact test for the lanes in a_und: the planes of the child just tested are read again
       const uint32_t c_cur = (a_rmeta >> 24) & 7u;
@@ -231,7 +241,20 @@ __device__ __forceinline__ uint64_t walk_asm(const float4* nodes, uint32_t varia
         else { hit.bet = bet; hit.gam = gam; }
       }
     }
+#ifdef RT_WAVE_TIMES_CLK
+    dbg_out += __builtin_amdgcn_s_memtime() - dbg_t0;
+#endif
   }
+#ifdef RT_WAVE_TIMES_CLK
+  // diagnostic build: per workgroup, behind the waves' records in the `t` output: exits for the exact node test, exits for
+  // triangle candidates, sixteenths of the cycles spent outside the block between exit and re-entry, walks
+  if (float* const ts = rt_dbg_ts()) {
+    if (fresh_lane_id() == 0) {
+      uint32_t* const dbg = (uint32_t*)ts + (1u << 22) + 4u * blockIdx.x;
+      atomicAdd(dbg + 0, dbg_n1); atomicAdd(dbg + 1, dbg_n2); atomicAdd(dbg + 2, (uint32_t)(dbg_out >> 4)); atomicAdd(dbg + 3, 1u);
+    }
+  }
+#endif
 #ifdef RT_WALK_PRIO
   rt_walk_work = a_work;
 #endif
@@ -1067,6 +1090,9 @@ __device__ __forceinline__ T late_struct(size_t offset) {
   return v;
 }
 #define LATE_STRUCT(field) late_struct<decltype(RtWaveArgs::field)>(offsetof(RtWaveArgs, field))
+#ifdef RT_WAVE_TIMES_CLK
+__device__ __forceinline__ float* rt_dbg_ts() { return LATE(ts); }
+#endif
 
 // DENSE (plain variant only): compiled for one more wave per SIMD, at the price of spilled registers in the shading code.
 // It pays for big frames of a heavy mesh, whose walks dominate (meshDragon 4K: 2.71 -> 2.61 ms), not for small frames
@@ -1162,6 +1188,9 @@ __global__ __launch_bounds__(RT_WBLOCK, (BOUNCE && !QPRIMARY) ? RT_WAVES_PER_SIM
   // Diagnostic build: every wave leaves (start, end) of its life on the 100 MHz clock and where it ran in the `t`
   // output, four words per wave in launch order (tools/wave_times.py); the per-pixel t is not written then.
   const unsigned long long wt_start = __builtin_amdgcn_s_memrealtime();
+#ifdef RT_WAVE_TIMES_CLK
+  const unsigned long long wt_clk0 = __builtin_amdgcn_s_memtime();   // (shader clock cycles: life in cycles / life in 10 ns = the clock the wave ran at)
+#endif
 #endif
 
   // view handed to the helpers of rt_kernels.h
@@ -1280,9 +1309,15 @@ __global__ __launch_bounds__(RT_WBLOCK, (BOUNCE && !QPRIMARY) ? RT_WAVES_PER_SIM
     }
     sh.view = tr_d;
   }
+#ifdef RT_WAVE_TIMES_CLK
+  unsigned long long wt_walk = 0ull; uint32_t wt_rounds = 0u;   // cycles inside the walks, rounds of the loop
+#endif
   while (__builtin_amdgcn_ballot_w64(phase != PH_DONE)) {
     // ---- trace the pending rays of the wave ---------------------------------------------------------
     Hit h = {RT_INF, -1, 0.f, 0.f};
+#ifdef RT_WAVE_TIMES_CLK
+    const unsigned long long wt_w0 = __builtin_amdgcn_s_memtime(); wt_rounds++;
+#endif
     bool traced = phase != PH_DONE;   // (trace_class may leave some of the wave's rays for the next round)
     {
       const bool want = phase != PH_DONE;
@@ -1301,6 +1336,9 @@ __global__ __launch_bounds__(RT_WBLOCK, (BOUNCE && !QPRIMARY) ? RT_WAVES_PER_SIM
       asm volatile("" ::: "memory");
       unpark<BOUNCE, TEX, QPRIMARY>(sh, MY_PARK());
     }
+#ifdef RT_WAVE_TIMES_CLK
+    wt_walk += __builtin_amdgcn_s_memtime() - wt_w0;
+#endif
     if (traced) count(N_TRACED);
     const rt_kernarg_ptr ka = late_args();   // one opaque copy for the whole shading phase: its loads go out together
     if (!traced) {
@@ -1530,6 +1568,11 @@ __global__ __launch_bounds__(RT_WBLOCK, (BOUNCE && !QPRIMARY) ? RT_WAVES_PER_SIM
     const uint32_t hw = __builtin_amdgcn_s_getreg((31 << 11) | (0 << 6) | 4), xcc = __builtin_amdgcn_s_getreg((31 << 11) | (0 << 6) | 20);
     uint32_t* o = (uint32_t*)ts + 4 * (size_t)((tile_of().y * LATE(tiles_x) + tile_of().x) * (RT_WBLOCK / 64) + (TID() >> 6));
     o[0] = (uint32_t)wt_start; o[1] = (uint32_t)wt_end; o[2] = hw; o[3] = xcc;
+#ifdef RT_WAVE_TIMES_CLK
+    // (-DRT_WAVE_TIMES_CLK, tools/exp_lone_wave_parts.py: the wave's life in shader clock cycles; sixteenths of the cycles it spent inside walks and the rounds of its main loop)
+    o[2] = (uint32_t)(__builtin_amdgcn_s_memtime() - wt_clk0);
+    o[3] = (uint32_t)(wt_walk >> 4) | (wt_rounds << 24);
+#endif
   }
 #endif
 

@@ -31,7 +31,7 @@ static void link(Tree& T, int& next, int& ro) {
 
 struct Sub { RtBundle B; bool on; uint64_t lanes; };          // one bundle and the rays (indices into the walk's ray list) it covers
 struct Strategy { const char* name; std::vector<Sub> subs; long tri_left = 0, leaves_left = 0, passes = 0; };
-struct Stats { long node_it = 0, leaves = 0, tri_it = 0; };
+struct Stats { long node_it = 0, leaves = 0, tri_it = 0, hit_it = 0, hit_lanes = 0, exact_nodes = 0; };
 
 static Sub make_sub(const std::vector<Ray>& rays, uint64_t lanes, bool shadow) {
   Sub s; s.lanes = lanes; s.on = false; memset(&s.B, 0, sizeof s.B);
@@ -82,10 +82,12 @@ static void walk(const Tree& T, int node, const std::vector<Ray>& rays, std::vec
       const float* v = &T.verts[9 * id];
       const float e1[3] = {v[3] - v[0], v[4] - v[1], v[5] - v[2]}, e2[3] = {v[6] - v[0], v[7] - v[1], v[8] - v[2]};
       S.tri_it++;
+      int hl = 0;
       for (size_t i = 0; i < rays.size(); i++) if ((m >> i) & 1) {
         float t, bb, gg;
-        if (rt_triangle_test({v[0], v[1], v[2]}, {e1[0], e1[1], e1[2]}, {e2[0], e2[1], e2[2]}, rays[i].e, rays[i].d, hits[i].t, t, bb, gg)) hits[i] = {t, id, bb, gg};
+        if (rt_triangle_test({v[0], v[1], v[2]}, {e1[0], e1[1], e1[2]}, {e2[0], e2[1], e2[2]}, rays[i].e, rays[i].d, hits[i].t, t, bb, gg)) { hits[i] = {t, id, bb, gg}; hl++; }
       }
+      if (hl) { S.hit_it++; S.hit_lanes += hl; }
     }
     for (size_t i = 0; i < rays.size(); i++) if (((m >> i) & 1) && rays[i].stop >= 0.f && hits[i].t < rays[i].stop) live &= ~(1ull << i);
   }
@@ -138,12 +140,12 @@ int main(int ac, char** av) {
     return st;
   };
   auto add = [&](Totals& t, const Stats& S, const std::vector<Strategy>& st) {
-    t.S.node_it += S.node_it; t.S.leaves += S.leaves; t.S.tri_it += S.tri_it; t.walks++;
+    t.S.node_it += S.node_it; t.S.leaves += S.leaves; t.S.tri_it += S.tri_it; t.S.hit_it += S.hit_it; t.S.hit_lanes += S.hit_lanes; t.walks++;
     if (t.st.empty()) { t.st = st; for (auto& s : t.st) { s.subs.clear(); s.tri_left = s.leaves_left = s.passes = 0; } }
     for (size_t i = 0; i < st.size(); i++) { t.st[i].tri_left += st[i].tri_left; t.st[i].leaves_left += st[i].leaves_left; t.st[i].passes += st[i].passes; }
   };
   auto show = [&](const char* what, const Stats& S, const std::vector<Strategy>& st, const std::vector<Strategy>* detail) {
-    printf("  %-10s node it %ld leaves %ld tri it %ld |", what, S.node_it, S.leaves, S.tri_it);
+    printf("  %-10s node it %ld leaves %ld tri it %ld (with an accepted hit: %ld, lanes %ld) |", what, S.node_it, S.leaves, S.tri_it, S.hit_it, S.hit_lanes);
     for (const auto& s : st) printf(" %s %ld/%ld(p%ld)", s.name, s.tri_left, s.leaves_left, s.passes);
     // crude cost in issued instructions: 20 per node iteration, 40 per pass of the bundle test, 25 per triangle iteration
     printf("\n  %-10s cost k-instr:", "");

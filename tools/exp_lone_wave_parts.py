@@ -44,5 +44,10 @@ for what, path in cases:
         start = raw[:, 0].astype(np.int64); end = raw[:, 1].astype(np.int64)
         end = np.where(end < start, end + (1 << 32), end)
         dur = (end - start) / 100.0
-        print("%-24s %-15s kernel %.3f ms; tile 283: %4.0f us, tile 284: %4.0f us, tile 271: %4.0f us; mean %.1f; rays traced %d" % (
-            what, fl, st["kernel_ms"], dur[283], dur[284], dur[271], dur.mean(), st["rays_traced"]))
+        clk = ""
+        if os.environ.get("RT_EXP_CLK"):   # (build with -DRT_WAVE_TIMES_CLK: word 2 of a wave's record is its life in shader clock cycles)
+            dbg = ts.cpu().numpy().view(np.uint32).reshape(-1)[(1 << 22) + 4 * 283:(1 << 22) + 4 * 283 + 4]
+            clk = "; exits: %d exact node tests, %d triangle candidates, %.0f %% of the cycles between exit and re-entry, %d walks" % (dbg[0], dbg[1], 100.0 * (int(dbg[2]) << 4) / raw[283, 2], dbg[3])
+            clk += "; tile 283 ran at %.0f MHz, %.0f %% of its cycles inside %d walks" % (raw[283, 2] / dur[283], 100.0 * ((raw[283, 3] & 0xffffff) << 4) / raw[283, 2], raw[283, 3] >> 24)
+        print("%-24s %-15s kernel %.3f ms; tile 283: %4.0f us, tile 284: %4.0f us, tile 271: %4.0f us; mean %.1f; rays traced %d%s" % (
+            what, fl, st["kernel_ms"], dur[283], dur[284], dur[271], dur.mean(), st["rays_traced"], clk))
