@@ -49,7 +49,7 @@ def parse_args():
     return ap.parse_args()
 
 
-def committed_counters(source_sha256):
+def committed_counters(source_sha256, workload=None):
     """The rocprofv3 counter passes committed under profiles/ (r*_counters.json, tools/profile_to_json.py), if they were
     taken with exactly the kernel sources that are running now (digest of the source files recorded in the profile);
     hardware counters cannot be read from inside the benchmark, and numbers of other code are not quoted: None then."""
@@ -60,7 +60,7 @@ def committed_counters(source_sha256):
                 j = json.load(f)
         except (OSError, ValueError):
             continue
-        if j.get("source_sha256") == source_sha256:
+        if j.get("source_sha256") == source_sha256 and (workload is None or j.get("workload") == workload):
             j["file"] = os.path.relpath(path, ROOT)
             return j
     return None
@@ -261,8 +261,9 @@ def main():
             ach = flop / world / (t_ms * 1e-3) / 1e12
             # The path is neither a dense contraction nor memory-bound: the roof that binds is FP32 vector issue.  The HBM
             # view is reported beside it (hbm_*): measured bytes per launch over the same kernel time, against 8 TB/s.
-            headline = world == 1 and not share_of and W == 3840 and H == 2160 and args.scene.endswith("meshDragon.json") and args.depth == 3
-            prof = committed_counters(rt.kernel_source_sha256()) if headline else None
+            # (counter passes are committed per workload: the headline frame, and the other configurations at 3840x2160)
+            workload = "%s %dx%d depth %d" % (os.path.join("scenes", os.path.basename(args.scene)), W, H, args.depth)
+            prof = committed_counters(rt.kernel_source_sha256(), workload) if (world == 1 and not share_of) else None
             roofline = {"bound": "valu_fp32", "achieved": ach, "peak": PEAK_FP32_TFLOPS, "unit": "TFLOP/s",
                         "frac": ach / PEAK_FP32_TFLOPS,
                         # (the kernel proves most triangle tests of a leaf rejected for a whole wave without executing them, and stops

@@ -198,7 +198,7 @@ struct rt_dscene {
   RenderCtx ctx;
 };
 
-extern "C" const char* rt_version(void) { return "rt_amd 2.3 gfx950 (wave-synchronous traversal in gfx950 assembly, exact division-free predicates, leaf triangles ruled out per wave)"; }
+extern "C" const char* rt_version(void) { return "rt_amd 3.0 gfx950 (wave-synchronous traversal in gfx950 assembly, exact division-free predicates, leaf triangles ruled out per wave)"; }
 
 extern "C" void rt_dscene_destroy(rt_dscene* d) {
   if (!d) return;

@@ -1,8 +1,9 @@
 #!/usr/bin/env python3
-"""Sum rocprofv3 --pmc counters (CSV output) per kernel over its dispatches: `pmc_summary.py DIR [kernel-substring]`."""
+"""Sum rocprofv3 --pmc counters (CSV output) per kernel over its dispatches: `pmc_summary.py DIR [kernel-regex]`."""
 import collections
 import csv
 import glob
+import re
 import sys
 
 
@@ -11,8 +12,8 @@ def main(d, needle="render_"):
     ndisp = collections.defaultdict(set)
     for path in glob.glob(d + "/*counter_collection.csv"):
         for r in csv.DictReader(open(path)):
-            if needle in r["Kernel_Name"]:
-                k = r["Kernel_Name"].split("(")[0][:60]
+            if re.search(needle, r["Kernel_Name"]):
+                k = r["Kernel_Name"].replace("(anonymous namespace)::", "").replace("void ", "").split("(")[0][:80]
                 agg[k][r["Counter_Name"]] += float(r["Counter_Value"])
                 ndisp[k].add(r["Dispatch_Id"])
                 agg[k]["_vgpr"] = float(r["VGPR_Count"]); agg[k]["_sgpr"] = float(r["SGPR_Count"])
