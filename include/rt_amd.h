@@ -88,7 +88,11 @@ enum {
   /* Test every triangle of every leaf a ray enters, as octtree.cu:264-274 does.  Without this flag a wave first rules out
    * the triangles of a leaf that none of its rays can be accepted by (same bytes: a test that rejects changes nothing);
    * the flag is there for cross-checks and measurements. */
-  RT_RENDER_EVERY_TRIANGLE = 64
+  RT_RENDER_EVERY_TRIANGLE = 64,
+  /* rt_frame_enqueue only: leave the finished frame in device memory (rt_frame_device_image) and skip the copy to the
+   * host, for callers that go on working with it on the GPU (display interop, an encoder): a 3840x2160 frame is 24.9 MB,
+   * and over PCIe its copy can take longer than its render. */
+  RT_FRAME_ON_DEVICE = 128
 };
 
 /* Parse resources + scene, load and transform meshes, build the octree.
@@ -265,6 +269,9 @@ int rt_frame_enqueue(rt_frame_ctx* f, int slot, unsigned flags);
 /* *h_rgb: the slot's page-locked frame (W*H*3 bytes, valid until the slot is enqueued again); *frame_ms: first launch to
  * the frame in host memory, from events on the first device's stream.  Either may be NULL. */
 int rt_frame_wait(rt_frame_ctx* f, int slot, const uint8_t** h_rgb, float* frame_ms);
+/* The slot's frame in the memory of scenes[0]'s device (W*H*3 bytes; complete after rt_frame_wait, valid until the slot is
+ * enqueued again).  With RT_FRAME_ON_DEVICE it is the only copy, and rt_frame_wait's *h_rgb is NULL. */
+int rt_frame_device_image(rt_frame_ctx* f, int slot, uint8_t** d_rgb);
 
 /* Decode a texture image (8-bit non-interlaced PNG, baseline JPEG) to RGB8, row 0 on top: the loader behind the
  * `textures` of resources.json.  The reference's own loader is an unfinished stub (material/material.cu:276-289).

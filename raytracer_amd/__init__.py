@@ -26,6 +26,7 @@ RT_RENDER_STACKED = 8
 RT_RENDER_QUEUED = 16
 RT_RENDER_STRIPS = 32
 RT_RENDER_EVERY_TRIANGLE = 64
+RT_FRAME_ON_DEVICE = 128
 
 # Every symbol include/rt_amd.h declares.
 ABI_SYMBOLS = (
@@ -34,7 +35,7 @@ ABI_SYMBOLS = (
     "rt_host_alloc", "rt_host_free", "rt_band_count", "rt_render_bands", "rt_dscene_get_info",
     "rt_comm_unique_id", "rt_comm_init_rank", "rt_comm_init_all", "rt_comm_destroy", "rt_comm_group_begin", "rt_comm_group_end",
     "rt_gather_bands", "rt_unpack_bands", "rt_render_frame_gathered",
-    "rt_frame_ctx_create", "rt_frame_ctx_destroy", "rt_frame_enqueue", "rt_frame_wait",
+    "rt_frame_ctx_create", "rt_frame_ctx_destroy", "rt_frame_enqueue", "rt_frame_wait", "rt_frame_device_image",
     "rt_write_png", "rt_image_load", "rt_strerror", "rt_last_error", "rt_version",
 )
 
@@ -164,6 +165,7 @@ def lib():
         L.rt_frame_ctx_destroy.restype = None
         L.rt_frame_enqueue.argtypes = [C.c_void_p, C.c_int, C.c_uint]
         L.rt_frame_wait.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_void_p), C.POINTER(C.c_float)]
+        L.rt_frame_device_image.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_void_p)]
         L.rt_write_png.argtypes = [C.c_char_p, C.c_int, C.c_int, C.c_void_p]
         L.rt_image_load.argtypes = [C.c_char_p, C.POINTER(C.c_int), C.POINTER(C.c_int), C.c_void_p, C.c_size_t]
         L.rt_strerror.argtypes = [C.c_int]
@@ -409,9 +411,17 @@ class FramePipeline:
         buffer, valid until the slot is enqueued again) and its first-launch-to-host time in ms."""
         p, ms = C.c_void_p(), C.c_float()
         _check(lib().rt_frame_wait(self.h, slot, C.byref(p), C.byref(ms)))
+        if not p.value:                 # enqueued with RT_FRAME_ON_DEVICE: the frame stayed in device memory (device_image)
+            return None, ms.value
         buf = (C.c_ubyte * (self.width * self.height * 3)).from_address(p.value)
         a = np.frombuffer(buf, np.uint8).reshape(self.height, self.width, 3)
         return (a.copy() if copy else a), ms.value
+
+    def device_image(self, slot):
+        """Device address of the slot's frame (W*H*3 bytes on the first device)."""
+        p = C.c_void_p()
+        _check(lib().rt_frame_device_image(self.h, slot, C.byref(p)))
+        return p.value
 
     def close(self):
         if getattr(self, "h", None):

@@ -302,7 +302,7 @@ struct rt_frame_ctx {
     std::vector<uint8_t*> local;    // (n > 1, or a communicator was given: the device's packed bands)
     uint8_t* gathered = nullptr; uint8_t* image = nullptr; uint8_t* host = nullptr;
     hipEvent_t begin = nullptr, end = nullptr;
-    bool busy = false;
+    bool busy = false, on_device = false;
   };
   std::vector<Slot> slot;
 };
@@ -375,7 +375,7 @@ extern "C" int rt_frame_enqueue(rt_frame_ctx* f, int slot, unsigned flags) {
   if (!f || slot < 0 || slot >= (int)f->slot.size()) { rt_set_error("rt_frame_enqueue: bad argument"); return RT_ERR_ARG; }
   rt_frame_ctx::Slot& S = f->slot[slot];
   if (S.busy) { rt_set_error("rt_frame_enqueue: the slot's last frame has not been waited for"); return RT_ERR_ARG; }
-  const unsigned render_flags = flags & ~(unsigned)RT_RENDER_TIME;
+  const unsigned render_flags = flags & ~(unsigned)(RT_RENDER_TIME | RT_FRAME_ON_DEVICE);
   { DeviceScope g(f->dev[0]); if (hipEventRecord(S.begin, S.stream[0]) != hipSuccess) { rt_set_error("rt_frame_enqueue: event record failed"); return RT_ERR_DEVICE; } }
   int rc = RT_OK;
   if (f->comms.empty()) {   // one device, no exchange: straight into the frame
@@ -395,7 +395,8 @@ extern "C" int rt_frame_enqueue(rt_frame_ctx* f, int slot, unsigned flags) {
     if (rc != RT_OK) return rc;
   }
   DeviceScope g(f->dev[0]);
-  if (hipMemcpyAsync(S.host, S.image, f->frame_bytes, hipMemcpyDeviceToHost, S.stream[0]) != hipSuccess ||
+  S.on_device = (flags & RT_FRAME_ON_DEVICE) != 0;
+  if ((!S.on_device && hipMemcpyAsync(S.host, S.image, f->frame_bytes, hipMemcpyDeviceToHost, S.stream[0]) != hipSuccess) ||
       hipEventRecord(S.end, S.stream[0]) != hipSuccess) { rt_set_error("rt_frame_enqueue: copy to the host failed"); return RT_ERR_DEVICE; }
   S.busy = true;
   return RT_OK;
@@ -409,6 +410,12 @@ extern "C" int rt_frame_wait(rt_frame_ctx* f, int slot, const uint8_t** h_rgb, f
   if (hipEventSynchronize(S.end) != hipSuccess) { rt_set_error("rt_frame_wait: the frame failed"); return RT_ERR_DEVICE; }
   S.busy = false;
   if (frame_ms) { float ms = 0.f; if (hipEventElapsedTime(&ms, S.begin, S.end) != hipSuccess) ms = 0.f; *frame_ms = ms; }
-  if (h_rgb) *h_rgb = S.host;
+  if (h_rgb) *h_rgb = S.on_device ? nullptr : S.host;
+  return RT_OK;
+}
+
+extern "C" int rt_frame_device_image(rt_frame_ctx* f, int slot, uint8_t** d_rgb) {
+  if (!f || !d_rgb || slot < 0 || slot >= (int)f->slot.size()) { rt_set_error("rt_frame_device_image: bad argument"); return RT_ERR_ARG; }
+  *d_rgb = f->slot[slot].image;
   return RT_OK;
 }

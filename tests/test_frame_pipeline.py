@@ -47,6 +47,16 @@ def test_frames_in_flight_are_the_frame_rendered_alone(name, w, h, exchange):
     for r in range(n):
         torch.cuda.synchronize(r)
         assert torch.cuda.mem_get_info(r)[0] == free0[r], "device %d: memory was allocated or freed by the per-frame calls" % r
+    # a frame left on the device: no host copy, the same bytes in the slot's device image
+    pipe.enqueue(1, rt.RT_FRAME_ON_DEVICE)
+    none, ms = pipe.wait(1)
+    assert none is None and ms > 0
+    dev_img = torch.empty((h, w, 3), dtype=torch.uint8, device="cuda:0")
+    import ctypes
+    import os
+    hip = ctypes.CDLL(os.path.join(os.path.dirname(torch.__file__), "lib", "libamdhip64.so"))   # (the runtime torch and the library share)
+    rc = hip.hipMemcpy(ctypes.c_void_p(dev_img.data_ptr()), ctypes.c_void_p(pipe.device_image(1)), ctypes.c_size_t(h * w * 3), 3)   # 3: device to device
+    assert rc == 0 and np.array_equal(dev_img.cpu().numpy(), want)
     # misuse is refused, not raced
     pipe.enqueue(0)
     with pytest.raises(rt.RtError):
