@@ -986,6 +986,12 @@ enum { PH_CLOSEST = 0, PH_SHADOW = 1, PH_DONE = 2, PH_SHADE = 3 };
 #ifndef RT_WAVES_PER_SIMD_QPRIMARY
 #define RT_WAVES_PER_SIMD_QPRIMARY 4   // (glass bunny 4K: 5.18 ms at five waves, 5.11 at four: the dielectric shading code wants the registers)
 #endif
+#ifndef RT_WAVES_PER_SIMD_SPHERES
+#define RT_WAVES_PER_SIMD_SPHERES 5          // the variants for scenes without a mesh
+#endif
+#ifndef RT_WAVES_PER_SIMD_SPHERES_BOUNCE
+#define RT_WAVES_PER_SIMD_SPHERES_BOUNCE 4
+#endif
 #define RT_WAVES_PER_SIMD_QPRIMARY_OR_PLAIN(q) ((q) ? RT_WAVES_PER_SIMD_QPRIMARY : RT_WAVES_PER_SIMD)
 
 // Shading state of a lane.  It is dead while the wave traverses the octree, and the traversal is where
@@ -1100,8 +1106,10 @@ __device__ __forceinline__ float* rt_dbg_ts() { return LATE(ts); }
 // TEX: the scene has texture materials (two more words of shading state, a texel fetch per material and light: variants
 // of their own, so that every other scene runs the kernels it ran before).
 // QPRIMARY (with QUEUES): the launch casts the primary rays; without it a QUEUES launch renders a queue.
-template <bool BOUNCE, bool COUNT, bool QUEUES, bool DENSE = false, bool TEX = false, bool QPRIMARY = false>
-__global__ __launch_bounds__(RT_WBLOCK, (BOUNCE && !QPRIMARY) ? RT_WAVES_PER_SIMD_BOUNCE : (DENSE ? RT_WAVES_PER_SIMD + 1 : RT_WAVES_PER_SIMD_QPRIMARY_OR_PLAIN(QPRIMARY))) void render_wave(
+// MESH = false: variants for scenes without a mesh (no octree): no walk is compiled in, and the shading state is not parked.
+template <bool BOUNCE, bool COUNT, bool QUEUES, bool DENSE = false, bool TEX = false, bool QPRIMARY = false, bool MESH = true>
+__global__ __launch_bounds__(RT_WBLOCK, !MESH ? (BOUNCE ? RT_WAVES_PER_SIMD_SPHERES_BOUNCE : RT_WAVES_PER_SIMD_SPHERES)
+                                              : ((BOUNCE && !QPRIMARY) ? RT_WAVES_PER_SIMD_BOUNCE : (DENSE ? RT_WAVES_PER_SIMD + 1 : RT_WAVES_PER_SIMD_QPRIMARY_OR_PLAIN(QPRIMARY)))) void render_wave(
     const float4* __restrict__ nodes, const float4* __restrict__ tri_leaf, const RtWaveArgs A) {
   const RtSphere* __restrict__ spheres = A.spheres;
   const int n_spheres = A.n_spheres, has_oct = A.has_oct, n_wnodes = A.n_wnodes;
@@ -1323,6 +1331,22 @@ __global__ __launch_bounds__(RT_WBLOCK, (BOUNCE && !QPRIMARY) ? RT_WAVES_PER_SIM
       const bool want = phase != PH_DONE;
       // the instrumented variant walks shadow rays to the end, as the reference does, so that its test counts match
       const float stop_t = (phase == PH_SHADOW && !COUNT) ? tr_stop : -1.f;
+      if constexpr (!MESH) {
+        // A scene without a mesh: the closest hit is the loop over the spheres (ray.cu:52-53) and nothing else.  No walk needs
+        // the registers, so the shading state stays where it is instead of going to LDS and back around every ray
+        // (36 words each way for the variants with bounce rays: a third of what a round of a sphere scene issued).
+        if ((COUNT || RT_PATHS_ON) && __builtin_amdgcn_ballot_w64(want)) tl.w[0]++;
+        bool mine_live = want;
+        for (int32_t s = 0; s < n_spheres; s++) {
+          if (mine_live) {
+            if (COUNT) tl.sph++;
+            if (rt_sphere_test(ld3(spheres[s].c), spheres[s].r, tr_e, tr_d, h.t)) {
+              h.prim = -2 - s;
+              if (stop_t >= 0.f && h.t < stop_t) mine_live = false;
+            }
+          }
+        }
+      } else {
       park<BOUNCE, TEX, QPRIMARY>(sh, MY_PARK());
       asm volatile("" ::: "memory");
       if (LANES) trace_lanes(nodes, LATE(node_skip), tri_leaf, spheres, n_spheres, has_oct != 0, want, tr_e, tr_d, stop_t, h);
@@ -1335,6 +1359,7 @@ __global__ __launch_bounds__(RT_WBLOCK, (BOUNCE && !QPRIMARY) ? RT_WAVES_PER_SIM
       else trace_wave<COUNT, !queued && !COUNT>(nodes, n_wnodes, tri_leaf, spheres, n_spheres, has_oct != 0, want, tr_e, tr_d, stop_t, h, st, LANE(), tl, cull_sh + 16 * (TID() >> 6), COUNT ? 0u : LATE(cull_offset), LATE(cull_r0_max), LATE(cull_ksp_max) RT_WORK_ARG);
       asm volatile("" ::: "memory");
       unpark<BOUNCE, TEX, QPRIMARY>(sh, MY_PARK());
+      }
     }
 #ifdef RT_WAVE_TIMES_CLK
     wt_walk += __builtin_amdgcn_s_memtime() - wt_w0;
@@ -1438,6 +1463,20 @@ __global__ __launch_bounds__(RT_WBLOCK, (BOUNCE && !QPRIMARY) ? RT_WAVES_PER_SIM
               // material of this hit gets the verdict of the ray already traced (the instrumented variant
               // re-traces, to count what the reference does)
               occluded = (sh.vis_occluded >> li) & 1u;
+            } else if constexpr (!MESH) {
+              // no mesh: the shadow ray is the loop over the spheres, traced on the spot (ray.cu:56-72) instead of in a round of
+              // its own (which would work the light's direction and distance out a second time when the verdict comes back)
+              float st = RT_INF;
+              bool looking = true;
+              for (int32_t sp = 0; sp < n_spheres; sp++) {
+                if (looking) {
+                  if (COUNT) tl.sph++;
+                  if (rt_sphere_test(ld3(spheres[sp].c), spheres[sp].r, sP, l, st) && !COUNT && st < ldist) looking = false;   // (the instrumented variant tests them all, as the reference does)
+                }
+              }
+              occluded = ldist > st;   // ray.cu:70
+              count(N_TRACED);
+              if (!COUNT && li < 32) { sh.vis_known |= 1u << li; if (occluded) sh.vis_occluded |= 1u << li; }
             } else {
               tr_e = sP; tr_d = l; tr_stop = ldist; phase = PH_SHADOW;
               break;
@@ -1609,7 +1648,9 @@ int rt_preload_wave_kernels() {
       reinterpret_cast<const void*>(&render_wave<true, true, true>), reinterpret_cast<const void*>(&render_wave<true, false, true, false, false, true>),
       reinterpret_cast<const void*>(&render_wave<true, true, true, false, false, true>), reinterpret_cast<const void*>(&render_wave<false, false, false, false, true>),
       reinterpret_cast<const void*>(&render_wave<false, true, false, false, true>), reinterpret_cast<const void*>(&render_wave<true, false, false, false, true>),
-      reinterpret_cast<const void*>(&render_wave<true, true, false, false, true>)};
+      reinterpret_cast<const void*>(&render_wave<true, true, false, false, true>),
+      reinterpret_cast<const void*>(&render_wave<false, false, false, false, false, false, false>), reinterpret_cast<const void*>(&render_wave<false, true, false, false, false, false, false>),
+      reinterpret_cast<const void*>(&render_wave<true, false, false, false, false, false, false>), reinterpret_cast<const void*>(&render_wave<true, true, false, false, false, false, false>)};
   for (const void* k : kernels) { const hipError_t e = hipFuncGetAttributes(&attr, k); if (e != hipSuccess) return (int)e; }
   return (int)hipSuccess;
 }
@@ -1669,6 +1710,11 @@ void rt_launch_wave_kernel(const RtDeviceView& V, const RowMap& rows, bool bounc
     else hipLaunchKernelGGL((render_wave<true, false, true, false, false, true>), grid, block, 0, stream, V.wnodes, V.tri_leaf, A);
   }
   else if (wf.enabled) { if (count) LAUNCH(true, true, true); else LAUNCH(true, false, true); }
+  else if (!V.has_oct) {   // a scene of spheres only: the variants without a walk
+#define LAUNCH_SPHERES(B, C) hipLaunchKernelGGL((render_wave<B, C, false, false, false, false, false>), grid, block, 0, stream, V.wnodes, V.tri_leaf, A)
+    if (bounce && count) LAUNCH_SPHERES(true, true); else if (bounce) LAUNCH_SPHERES(true, false); else if (count) LAUNCH_SPHERES(false, true); else LAUNCH_SPHERES(false, false);
+#undef LAUNCH_SPHERES
+  }
   else if (bounce && count) LAUNCH(true, true, false);
   else if (bounce) LAUNCH(true, false, false);
   else if (count) LAUNCH(false, true, false);
