@@ -198,7 +198,21 @@ struct rt_dscene {
   RenderCtx ctx;
 };
 
-extern "C" const char* rt_version(void) { return "rt_amd 3.0 gfx950 (wave-synchronous traversal in gfx950 assembly, exact division-free predicates, leaf triangles ruled out per wave)"; }
+// The library's name and version; when RT_AMD_* variables are set in the environment (they move thresholds and switch
+// parts of the kernels off, for measurements) they are named behind it, so that no line of a benchmark or of `run --stats`
+// is ever taken with a non-default setting without saying so.
+extern char** environ;
+extern "C" const char* rt_version(void) {
+  static const std::string text = [] {
+    std::string v = "rt_amd 3.0 gfx950 (wave-synchronous traversal in gfx950 assembly, exact division-free predicates, leaf triangles ruled out per wave)";
+    std::string knobs;
+    for (char** e = environ; e && *e; e++)
+      if (!strncmp(*e, "RT_AMD_", 7) && strncmp(*e, "RT_AMD_LIB=", 11) && strncmp(*e, "RT_AMD_BUILD_THREADS=", 21)) { knobs += knobs.empty() ? "" : " "; knobs += *e; }
+    if (!knobs.empty()) v += " [non-default: " + knobs + "]";
+    return v;
+  }();
+  return text.c_str();
+}
 
 extern "C" void rt_dscene_destroy(rt_dscene* d) {
   if (!d) return;

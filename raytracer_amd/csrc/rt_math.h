@@ -546,8 +546,13 @@ RT_HD void rt_node_slab_class2(const RtVec3& lo, const RtVec3& hi, const RtVec3&
 // What R' has to be for "the line misses the ball" to imply "triangle.cu:107-152 rejects", in float arithmetic:
 // with b = eye - v0, n = e1 x e2 and det = -d.n, the reference accepts only if its rounded numerators satisfy
 // 0 <= nb / det, 0 <= ng / det and 1 - nb / det - ng / det >= 0.  The rounded numerators differ from the exact ones by at
-// most E_b = c u |b||e2|, E_g = c u |b||e1|, E_d = c u |e1||e2| (u = 2^-24; c < 10 from the operation count of
-// rt_cofactor_solve).  If |det| >= tau > 2 E_d the computed det has the exact one's sign, and acceptance implies for the
+// most E_b = c u |b||e2|, E_g = c u |b||e1|, E_d = c u |e1||e2| (u = 2^-24; c <= 6 sqrt(2) < 10, operation by operation:
+// a numerator of rt_cofactor_solve is (p x q) . r with p, q, r two of e1, e2, -d and b.  Each component of the cross product is
+// two rounded products and a rounded difference: off by at most 2u (|p_j q_k| + |p_k q_j|) (1 + O(u)), and the vector A of those
+// sums has |A| <= sqrt(2) |p||q|.  The dot product with r is three rounded products and two rounded sums: every term carries
+// at most three more roundings, b's components one of their own (eye - v0); together |computed - exact| <=
+// (2u + 3u + u) sum_i |r_i| A_i (1 + O(u)) <= 6 sqrt(2) u |p||q||r|, with |d| <= 1 + 2^-22.  No operand is near the underflow
+// threshold in a scene that fits the +-16 root cube unless the triangle is degenerate, and those carry Q = +inf below).  If |det| >= tau > 2 E_d the computed det has the exact one's sign, and acceptance implies for the
 // exact solution beta >= -E_b / tau, gamma >= -E_g / tau, beta + gamma <= 1 + 2u + (E_b + E_g + 2 E_d) / tau: the
 // point where the line meets the triangle's plane lies in the triangle scaled about its centroid by 1 + 3 mu,
 // mu = c u (|b| (|e1| + |e2|) + 2 |e1||e2|) / tau, hence in the ball of radius R (1 + 3 mu) about the centroid (R: the

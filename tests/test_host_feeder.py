@@ -125,3 +125,20 @@ def test_tree_does_not_depend_on_the_number_of_build_threads(monkeypatch):
         trees.append((k.copy(), b.copy(), r.copy()))
     for k, b, r in trees[1:]:
         assert np.array_equal(k, trees[0][0]) and np.array_equal(_bits(b), _bits(trees[0][1])) and np.array_equal(r, trees[0][2])
+
+
+def test_version_names_the_tunables_in_force():
+    # RT_AMD_* variables move thresholds and switch parts of the kernels off (measurements); a process that runs with any of
+    # them says so in its version string, which every bench line and `run --stats` line carries
+    import subprocess
+    import sys
+    code = "import sys; sys.path.insert(0, %r); import raytracer_amd as rt; print(rt.version())" % os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ)
+    for k in [k for k in env if k.startswith("RT_AMD_")]:
+        del env[k]
+    plain = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=60).stdout
+    assert "non-default" not in plain and plain.startswith("rt_amd ")
+    env["RT_AMD_NO_CULL"] = "1"
+    env["RT_AMD_CULL_MIN_NODES"] = "64"
+    knobs = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=60).stdout
+    assert "non-default" in knobs and "RT_AMD_NO_CULL=1" in knobs and "RT_AMD_CULL_MIN_NODES=64" in knobs
