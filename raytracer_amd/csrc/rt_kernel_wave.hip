@@ -1718,7 +1718,10 @@ void rt_launch_wave_kernel(const RtDeviceView& V, const RowMap& rows, bool bounc
   else if (bounce && count) LAUNCH(true, true, false);
   else if (bounce) LAUNCH(true, false, false);
   else if (count) LAUNCH(false, true, false);
-  else if (((uint64_t)A.tiles_x * A.tiles_y >= dense_min_tiles) && V.has_oct && V.n_wnodes >= 512 && !rows.small)   // a big frame of a big mesh: one more wave per SIMD
+  // (a caller that keeps several launches in flight, rows.strips, fills the chip between them: the sixth wave then pays from
+  //  launches half as large - the bands of one GPU of 4, 32 400 tiles, three in flight: 0.333 -> 0.306 ms per frame; of one GPU
+  //  of 8, 16 200 tiles: no gain)
+  else if (((uint64_t)A.tiles_x * A.tiles_y >= (rows.strips ? dense_min_tiles * 2 / 5 : dense_min_tiles)) && V.has_oct && V.n_wnodes >= 512 && !rows.small)   // a big frame of a big mesh: one more wave per SIMD
     hipLaunchKernelGGL((render_wave<false, false, false, true>), grid, block, 0, stream, V.wnodes, V.tri_leaf, A);
   else LAUNCH(false, false, false);
 #undef LAUNCH

@@ -10,9 +10,11 @@ import raytracer_amd as rt
 
 w, h = 3840, 2160
 ds0 = rt.DeviceScene(rt.Scene("scenes/meshDragon.json", w, h, 3))
+import os
+KS = tuple(int(x) for x in os.environ.get('RT_EXP_STREAMS', '1,2,3,4').split(','))
 for n in (8, 4, 2):
     nb = ds0.band_count(16, 0, n)
-    for k in (1, 2, 3, 4):
+    for k in KS:
         streams = [torch.cuda.Stream() for _ in range(k)]
         ctx = [ds0] + [ds0.fork() for _ in range(k - 1)]
         bufs = [torch.zeros((nb * 16, w, 3), dtype=torch.uint8, device="cuda") for _ in range(k)]
