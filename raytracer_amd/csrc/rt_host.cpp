@@ -417,6 +417,12 @@ struct TreeBuilder {
   rt_scene& sc;
   std::vector<TriAxes> axes;
   std::atomic<int> spare_threads{0};
+  // A set that no subdivision separates (more than 50 triangles through one point, or triangles as large as the root
+  // box) would grow eightfold per level: the first branch that hits the depth limit, or a tree whose leaves list more
+  // entries than any real mesh needs, ends the whole build.
+  std::atomic<bool> give_up{false};
+  std::atomic<int64_t> refs_total{0};
+  static constexpr int64_t REFS_LIMIT = int64_t(1) << 28;
   explicit TreeBuilder(rt_scene& s) : sc(s) {}
 
   struct Sub {                       // descendants of one node, in depth-first block order
@@ -424,6 +430,7 @@ struct TreeBuilder {
     std::vector<int32_t> refs;
     int max_depth = 0;
     bool too_deep = false;
+    bool too_large = false;
   };
 
   static void child_box(const float* ini, const float* end, int c, float* ci, float* ce) {   // octtree.cu:95-111
@@ -447,12 +454,14 @@ struct TreeBuilder {
   // Fills `self` (bounds already set) and appends its descendants to `out`; depth of the root is 0.
   void fill(RtNode& self, const std::vector<int32_t>& tris, int depth, bool force_branch, Sub& out) {
     if (depth > out.max_depth) out.max_depth = depth;
+    if (give_up.load(std::memory_order_relaxed)) { set_links(self, (int32_t)out.refs.size(), 0); return; }
     if (!force_branch && (int)tris.size() <= RT_LEAF_CAP) {
+      if (refs_total.fetch_add((int64_t)tris.size(), std::memory_order_relaxed) > REFS_LIMIT) { out.too_large = true; give_up = true; }
       set_links(self, (int32_t)out.refs.size(), (int32_t)tris.size());
       out.refs.insert(out.refs.end(), tris.begin(), tris.end());
       return;
     }
-    if (depth + 1 >= RT_OCT_STACK) { out.too_deep = true; set_links(self, (int32_t)out.refs.size(), 0); return; }
+    if (depth + 1 >= RT_OCT_STACK) { out.too_deep = true; give_up = true; set_links(self, (int32_t)out.refs.size(), 0); return; }
     const int32_t first = (int32_t)out.nodes.size();
     set_links(self, first, -1);
     float ini[3], end[3];
@@ -497,6 +506,7 @@ struct TreeBuilder {
       out.refs.insert(out.refs.end(), part[c].refs.begin(), part[c].refs.end());
       if (part[c].max_depth > out.max_depth) out.max_depth = part[c].max_depth;
       out.too_deep |= part[c].too_deep;
+      out.too_large |= part[c].too_large;
     }
   }
 
@@ -513,6 +523,8 @@ struct TreeBuilder {
     RtNode root{}; set_bounds(root, ini, end);
     Sub rest;
     fill(root, all, 0, true, rest);
+    if (rest.too_large)
+      throw Fail{RT_ERR_LIMIT, "octree leaves would list more than 2^28 triangles (the mesh does not separate under subdivision)"};
     if (rest.too_deep)
       throw Fail{RT_ERR_LIMIT, "octree would be deeper than the 20-entry traversal stack (more than 50 triangles meet in one point)"};
     // the root takes index 0 and its descendants follow: shift every link by one node

@@ -119,6 +119,43 @@ def test_scene_from_hand_made_arrays():
     assert i["n_triangles"] == 1 and i["n_spheres"] == 1 and i["n_lights"] == 1 and i["n_nodes"] == 9 and i["n_leaf_refs"] >= 1
 
 
+@pytest.mark.parametrize("bad", ["nan", "fan", "huge"])
+def test_mesh_that_no_subdivision_separates_is_refused_at_once(bad):
+    # 4000 triangles that every octant keeps whole: vertices that are not numbers, a fan through one point, or triangles as large as the root box.  Eight children per level, each with the full
+    # set, would be 8^19 nodes; the build has to stop at the first branch that reaches the depth limit.
+    import time
+    n = 4000
+    rng = np.random.default_rng(5)
+    v = rng.uniform(-1, 1, (n, 9)).astype(np.float32)
+    if bad == "nan":
+        v[:, 0] = np.nan
+    elif bad == "fan":
+        v[:, 0:3] = 0.25
+    else:
+        v *= np.float32(1e30)
+    d = rt.SceneDesc()
+    cam = rt.Scene("scenes/sphere.json", 32, 32, 3).describe().camera
+    C.memmove(C.byref(d.camera), C.byref(cam), C.sizeof(rt.CameraDesc))
+    lights = (rt.LightDesc * 1)(); lights[0].col[:] = [1, 1, 1]; lights[0].pos[:] = [0, 5, 5]
+    mats = (rt.MaterialDesc * 1)(); mats[0].col[:] = [1, 0, 0]
+    idx = (C.c_int32 * 1)(0)
+    verts = (C.c_float * (9 * n))(*v.ravel().tolist())
+    nrm = (C.c_float * (9 * n))(*([0.0, 1.0, 0.0] * (3 * n)))
+    tm = (C.c_int32 * n)()
+    mf, mc = (C.c_int32 * 1)(0), (C.c_int32 * 1)(1)
+    d.n_lights, d.n_materials, d.n_mat_index, d.n_spheres, d.n_meshes, d.n_triangles = 1, 1, 1, 0, 1, n
+    d.lights, d.materials, d.mat_index = lights, mats, idx
+    d.mesh_mat_first, d.mesh_mat_count, d.tri_verts, d.tri_normals, d.tri_mesh = mf, mc, verts, nrm, tm
+    t0 = time.time()
+    if bad == "nan":     # (no box keeps such a triangle: the scene is made, with nothing in its leaves)
+        assert rt.Scene.from_desc(d).info()["n_leaf_refs"] == 0
+    else:
+        with pytest.raises(rt.RtError) as e:
+            rt.Scene.from_desc(d)
+        assert e.value.status == -4
+    assert time.time() - t0 < 20
+
+
 @pytest.mark.gpu
 @pytest.mark.parametrize("name,w,h", [("meshMedBunny", 256, 192), ("heliumAttenuatedSphere", 256, 192), ("meshTransparentBunny", 200, 136),
                                       ("meshDragon", 640, 360)])
