@@ -157,7 +157,10 @@ __device__ __forceinline__ uint64_t walk_asm(const float4* nodes, uint32_t varia
   uint64_t a_blk = (uint64_t)(uintptr_t)(nodes + 2 * (size_t)top_first);
   uint32_t a_rem = rem | 0x100u, a_first = top_first, a_idx = 0u, a_rfirst = 0u, a_rmeta = 0u, a_tcur = 0u, a_tend = 0u, a_res = 0u, a_prim = 0u, a_sp = 0u;
   uint64_t a_tmask = live, a_mine = live, a_live = live, a_acc = 0ull, a_und = 0ull, a_pass = 0ull, a_chg = 0ull;
-  const uint64_t a_nodes = (uint64_t)(uintptr_t)nodes, a_tri = (uint64_t)(uintptr_t)tri_leaf;
+  const uint64_t a_tri = (uint64_t)(uintptr_t)tri_leaf;
+  // (the loop with four record sets parks s[68:83] while its leaf is open and may leave for the quotients with records in
+  //  them: the node array's address is an operand that comes back changed, like the rest of that range)
+  uint64_t a_nodes = (uint64_t)(uintptr_t)nodes;
   const float cmax = rt_max3(fabsf(fc.x), fabsf(fc.y), fabsf(fc.z));
   float a_det = 0.f, a_nb = 0.f, a_ng = 0.f, a_nt = 0.f;
 #ifdef RT_WAVE_TIMES_CLK
@@ -165,7 +168,13 @@ __device__ __forceinline__ uint64_t walk_asm(const float4* nodes, uint32_t varia
 #endif
 #ifdef RT_WALK_PRIO
   uint32_t a_work = uni(rt_walk_work);   // measurement builds: leaves entered by the wave so far, over all its walks (see RT_PRIO_STEP in rt_trace_asm.inc)
-#define RT_PRIO_OPERAND , "+{s23}"(a_work)
+#define RT_PRIO_OPERAND , "+{s17}"(a_work)
+#elif defined(RT_STAGE_COUNT)
+  // measurement builds (with -DRT_WAVE_TIMES_CLK and a block generated with RT_GEN_COUNT=1): s17 counts the triangle iterations
+  // that went on to the second (low half) and third stage (high half), s14 the triangle (low half) and node iterations (high half)
+  // s15 the blocks of children entered (low half) and the leaves (high half), s16 the children that came to the margin test (low half) and the pops
+  uint32_t a_stage = 0u, a_iter = 0u, a_enter = 0u, a_tail = 0u;
+#define RT_PRIO_OPERAND , "+{s17}"(a_stage), "+{s14}"(a_iter), "+{s15}"(a_enter), "+{s16}"(a_tail)
 #else
 #define RT_PRIO_OPERAND
 #endif
@@ -175,29 +184,29 @@ __device__ __forceinline__ uint64_t walk_asm(const float4* nodes, uint32_t varia
     if constexpr (CULL) {
       asm volatile(RT_TRACE_ASM_CULL
           : "+{s[68:69]}"(a_blk), "+{s70}"(a_rem), "+{s71}"(a_first), "+{s[72:73]}"(a_tmask), "+{s[74:75]}"(a_mine), "+{s[76:77]}"(a_live),
-            "+{s78}"(a_idx), "+{s79}"(a_rfirst), "+{s80}"(a_rmeta), "+{s[94:95]}"(a_acc), "+{s[96:97]}"(a_und), "+{s[28:29]}"(a_pass),
+            "+{s78}"(a_idx), "+{s79}"(a_rfirst), "+{s80}"(a_rmeta), "+{s[34:35]}"(a_acc), "+{s[96:97]}"(a_und), "+{s[28:29]}"(a_pass),
             "+{s20}"(a_tcur), "+{s22}"(a_tend), "+{s[24:25]}"(a_chg), "+{s30}"(a_res), "+{s31}"(a_prim), "+{m0}"(a_sp) RT_PRIO_OPERAND,
             "+{v60}"(st.first), "+{v61}"(st.cur), "+{v62}"(st.mask_lo), "+{v63}"(st.mask_hi),
-            "={v32}"(a_det), "={v33}"(a_nb), "={v35}"(a_ng), "={v36}"(a_nt)
-          : "{s[82:83]}"(a_nodes), "{s[92:93]}"(a_tri), "{s18}"(zpat), "{s19}"(cull), "{v[40:41]}"(e_xy), "{v42}"(e.z), "{v[44:45]}"(c_zx), "{v[46:47]}"(c_yz),
+            "={v32}"(a_det), "={v33}"(a_nb), "={v35}"(a_ng), "={v36}"(a_nt), "+{s[82:83]}"(a_nodes)
+          : "{s[32:33]}"(a_tri), "{s18}"(zpat), "{s19}"(cull), "{v[40:41]}"(e_xy), "{v42}"(e.z), "{v[44:45]}"(c_zx), "{v[46:47]}"(c_yz),
             "{v[48:49]}"(c_yx), "{v50}"(inv.x), "{v51}"(inv.y), "{v52}"(inv.z), "{v53}"(fc.x), "{v54}"(fc.y), "{v55}"(fc.z), "{v56}"(cmax),
             "{v57}"(neg_eb), "{v58}"(hit.t), "{v59}"(stop_t),
             [b0] "s"(b0), [b1] "s"(b1), [b2] "s"(b2), [b3] "s"(b3), [b4] "s"(b4), [b5] "s"(b5), [b6] "s"(b6), [b7] "s"(b7), [b8] "s"(b8), [b9] "s"(b9)
-          : "s36", "s37", "s38", "s39", "s40", "s41", "s42", "s43", "s44", "s45", "s46", "s47", "s48", "s49", "s50", "s51", "s52", "s53", "s54", "s55",
+          : "s23", "s92", "s93", "s94", "s95", "s36", "s37", "s38", "s39", "s40", "s41", "s42", "s43", "s44", "s45", "s46", "s47", "s48", "s49", "s50", "s51", "s52", "s53", "s54", "s55",
             "s56", "s57", "s58", "s59", "s60", "s61", "s62", "s63", "s64", "s65", "s66", "s67", "s81", "s84", "s85", "s86", "s87", "s88", "s89", "s90",
             "s91", "s98", "s99", "s26", "s27", "s21", "v34", "v37", "v38", "v39", "v64", "v65", "v66", "v67", "v68", "v69", "v70", "v71", "v72", "v73", "v74",
             "v75", "v76", "v77", "v78", "v79", "vcc", "scc");
     } else {
       asm volatile(RT_TRACE_ASM_PLAIN
           : "+{s[68:69]}"(a_blk), "+{s70}"(a_rem), "+{s71}"(a_first), "+{s[72:73]}"(a_tmask), "+{s[74:75]}"(a_mine), "+{s[76:77]}"(a_live),
-            "+{s78}"(a_idx), "+{s79}"(a_rfirst), "+{s80}"(a_rmeta), "+{s[94:95]}"(a_acc), "+{s[96:97]}"(a_und), "+{s[28:29]}"(a_pass),
+            "+{s78}"(a_idx), "+{s79}"(a_rfirst), "+{s80}"(a_rmeta), "+{s[34:35]}"(a_acc), "+{s[96:97]}"(a_und), "+{s[28:29]}"(a_pass),
             "+{s20}"(a_tcur), "+{s22}"(a_tend), "+{s[24:25]}"(a_chg), "+{s30}"(a_res), "+{s31}"(a_prim), "+{m0}"(a_sp) RT_PRIO_OPERAND,
             "+{v60}"(st.first), "+{v61}"(st.cur), "+{v62}"(st.mask_lo), "+{v63}"(st.mask_hi),
-            "={v32}"(a_det), "={v33}"(a_nb), "={v35}"(a_ng), "={v36}"(a_nt)
-          : "{s[82:83]}"(a_nodes), "{s[92:93]}"(a_tri), "{s18}"(zpat), "{v[40:41]}"(e_xy), "{v42}"(e.z), "{v[44:45]}"(c_zx), "{v[46:47]}"(c_yz),
+            "={v32}"(a_det), "={v33}"(a_nb), "={v35}"(a_ng), "={v36}"(a_nt), "+{s[82:83]}"(a_nodes)
+          : "{s[32:33]}"(a_tri), "{s18}"(zpat), "{v[40:41]}"(e_xy), "{v42}"(e.z), "{v[44:45]}"(c_zx), "{v[46:47]}"(c_yz),
             "{v[48:49]}"(c_yx), "{v50}"(inv.x), "{v51}"(inv.y), "{v52}"(inv.z), "{v53}"(fc.x), "{v54}"(fc.y), "{v55}"(fc.z), "{v56}"(cmax),
             "{v57}"(neg_eb), "{v58}"(hit.t), "{v59}"(stop_t)
-          : "s36", "s37", "s38", "s39", "s40", "s41", "s42", "s43", "s44", "s45", "s46", "s47", "s48", "s49", "s50", "s51", "s52", "s53", "s54", "s55",
+          : "s23", "s92", "s93", "s94", "s95", "s36", "s37", "s38", "s39", "s40", "s41", "s42", "s43", "s44", "s45", "s46", "s47", "s48", "s49", "s50", "s51", "s52", "s53", "s54", "s55",
             "s56", "s57", "s58", "s59", "s60", "s61", "s62", "s63", "s64", "s65", "s66", "s67", "s81", "s84", "s85", "s86", "s87", "s88", "s89", "s90",
             "s91", "s98", "s99", "s26", "s27", "s21", "v34", "v37", "v38", "v39", "v64", "v65", "v66", "v67", "v68", "v69", "v70", "v71", "v72", "v73", "v74",
             "v75", "v76", "v77", "v78", "v79", "vcc", "scc");
@@ -252,6 +261,11 @@ __device__ __forceinline__ uint64_t walk_asm(const float4* nodes, uint32_t varia
     if (fresh_lane_id() == 0) {
       uint32_t* const dbg = (uint32_t*)ts + (1u << 22) + 4u * blockIdx.x;
       atomicAdd(dbg + 0, dbg_n1); atomicAdd(dbg + 1, dbg_n2); atomicAdd(dbg + 2, (uint32_t)(dbg_out >> 4)); atomicAdd(dbg + 3, 1u);
+#ifdef RT_STAGE_COUNT
+      uint32_t* const stg = (uint32_t*)ts + (1u << 22) + (1u << 20) + 8u * blockIdx.x;
+      atomicAdd(stg + 0, a_iter & 0xffffu); atomicAdd(stg + 1, a_stage & 0xffffu); atomicAdd(stg + 2, a_stage >> 16); atomicAdd(stg + 3, a_iter >> 16);
+      atomicAdd(stg + 4, a_enter & 0xffffu); atomicAdd(stg + 5, a_enter >> 16); atomicAdd(stg + 6, a_tail & 0xffffu); atomicAdd(stg + 7, a_tail >> 16);
+#endif
     }
   }
 #endif
@@ -386,15 +400,21 @@ __device__ __forceinline__ void trace_wave(const float4* __restrict__ nodes, int
     // branch's children, s70 children left (bit 8 always set: "child 8" is the record behind the block, requested but
     // never tested), s71 index of child 0, s[72:73] lanes that entered the branch, s[74:75] those of them still
     // undecided, s[76:77] undecided lanes of the wave, s78 child whose record is in s[84:91], s79/s80 links of the child
-    // just tested, s81 byte offset, s[82:83] node array, s[92:93] triangle array, s[94:95] accepted lanes, s[96:97] undecided lanes,
+    // just tested, s81 byte offset, s[82:83] node array, s[32:33] triangle array, s[34:35] accepted lanes, s[96:97] undecided lanes,
     // s[28:29] triangle candidates, s20 / s21 byte offsets of the triangle record under test and the next one to be tested, s22 offset
     // behind the leaf's last record (in a leaf whose triangles were put in front of the wave's bundle first: scratch), s[24:25] lanes
-    // whose hit changed in the leaf, s30 reason / re-entry (2 / 3: which of the two leaf loops), s31 id of the candidate triangle,
+    // whose hit changed in the leaf, s30 reason / re-entry (2 / 3 / 4: which of the leaf loops), s31 id of the candidate triangle,
     // s19 byte offset of the RtCullRec array (0: no bundle), s[98:99] within such a leaf the triangles still to be tested (outside
     // the block they wait in lanes 62 / 63 of v60), ten scalar operands for the bundle; v[40:59] the ray
     // (origin, negated direction in the pairs the first stage multiplies, inverse direction, e * inv, margin terms,
     // closest hit so far, shadow-ray length), v[60:63] the wave's stack, v32 v33 v35 v36 determinant and numerators
     // of a candidate, v34 v37:v39 v64:v79 scratch.
+    // A wave with a long life - one that has met 128 triangles in leaves with six or more to test; lane 60 of v60 counts them
+    // over all its walks - takes such leaves through a loop with FOUR record sets (re-entry 4): s[68:83] and s[84:99] hold
+    // records too, the traversal state that lives there waits in lanes 32 .. 44 of v61, s20 .. s23 are the leaf-relative
+    // indices of the records in the four sets, s[24:25] the triangles still to request, vcc_lo the leaf's first record
+    // (outside the block: lane 61 of v60).  Two records are tested while the next two are on their way: a scalar load
+    // takes such a wave about 400 cycles, a test 150, loads return out of order and the only wait is for all of them.
     if ((presorted || zpat != 0u) && FUSED && (rem & 0xffu) != 0u) {
       RtBundle bundle = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
       const uint32_t cull = (CULLABLE && cull_offset != 0u && wave_bundle(live, e, d, stop_t, bundle, cull_r0_max, cull_ksp_max)) ? cull_offset : 0u;

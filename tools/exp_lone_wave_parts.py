@@ -49,5 +49,9 @@ for what, path in cases:
             dbg = ts.cpu().numpy().view(np.uint32).reshape(-1)[(1 << 22) + 4 * 283:(1 << 22) + 4 * 283 + 4]
             clk = "; exits: %d exact node tests, %d triangle candidates, %.0f %% of the cycles between exit and re-entry, %d walks" % (dbg[0], dbg[1], 100.0 * (int(dbg[2]) << 4) / raw[283, 2], dbg[3])
             clk += "; tile 283 ran at %.0f MHz, %.0f %% of its cycles inside %d walks" % (raw[283, 2] / dur[283], 100.0 * ((raw[283, 3] & 0xffffff) << 4) / raw[283, 2], raw[283, 3] >> 24)
+        if os.environ.get("RT_EXP_STAGES"):   # (build with -DRT_STAGE_COUNT and a block generated with RT_GEN_COUNT=1)
+            for tile in (283, 284, 100):
+                stg = ts.cpu().numpy().view(np.uint32).reshape(-1)[(1 << 22) + (1 << 20) + 4 * tile:(1 << 22) + (1 << 20) + 4 * tile + 4]
+                clk += "; tile %d: %d node and %d triangle iterations, %d went on to stage 2, %d to stage 3" % (tile, stg[3], stg[0], stg[1], stg[2])
         print("%-24s %-15s kernel %.3f ms; tile 283: %4.0f us, tile 284: %4.0f us, tile 271: %4.0f us; mean %.1f; rays traced %d%s" % (
             what, fl, st["kernel_ms"], dur[283], dur[284], dur[271], dur.mean(), st["rays_traced"], clk))

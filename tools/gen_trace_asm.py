@@ -7,6 +7,7 @@ turn) and every register is named explicitly; rt_kernel_wave.hip includes the re
    python3 tools/gen_trace_asm.py        (from the repository root; the output is checked in)
 """
 import os
+import sys
 
 # ---- scalar registers owned by the block (see RT_TRACE_* operand list in rt_kernel_wave.hip) ----
 TA, TB = 36, 52                  # s[36:51], s[52:67]: two triangle records (RtTriLeaf, 16 words)
@@ -17,8 +18,7 @@ IDX, RFIRST, RMETA = "s78", "s79", "s80"   # child whose record is in (or on its
 NODES = ("s82", "s83")
 OFF = "s81"
 NX = 84                          # s[84:91]: node record
-TRI = ("s92", "s93")
-ACC, UND, NR = "s[94:95]", "s[96:97]", "s[98:99]"
+UND, NR = "s[96:97]", "s[98:99]"  # (TRI and ACC: below, outside the range that the loop with four record sets takes over)
 # The triangle records of a leaf are addressed by their byte offset from the start of the record array (a scene's records stay
 # below 4 GiB: rt_device.hip checks): TCUR / TNXT take turns as "offset of the record under test" and "offset of the record
 # behind it, which is on its way", TEND is the offset behind the leaf's last record.
@@ -32,6 +32,27 @@ SURV, JT = "s[98:99]", "s22"       # (SURV shares the registers of NR, which onl
 CULL = "s19"                     # byte offset of the RtCullRec array from the triangle records, 0: test every triangle
 CHG, T64, PASS = "s[24:25]", "s[26:27]", "s[28:29]"
 RES, RPRIM = "s30", "s31"
+
+# The leaf loop of a wave with a long life keeps FOUR records in flight (two being tested while the next two are on their way).  A scalar
+# load takes a lone wave some 400 cycles and its test 150, and loads return out of order, so that the only wait there is
+# waits for ALL of them: what hides the latency is the number of requests between two waits.  The two further record sets
+# are s[68:83] and s[84:99]: the traversal state that lives there is parked in lanes 32 .. 44 of ST_CUR while a leaf with
+# at least BIG triangles to test is open (smaller leaves keep the loops with two sets: parking costs what two tests cost).
+# TRI and ACC move out of that range for good; inside that loop SURVB is the mask of triangles still to request (bit 63: the
+# end marker), the J registers hold the leaf-relative index of the record in each set (63: none), RF = vcc_lo the leaf's first
+# record index, bit 30: the walk left this leaf for the quotients at least once (what CHG says in the other loops).
+BATCH = os.environ.get("RT_GEN_BATCH", "1") != "0"        # (RT_GEN_BATCH=0: the block without that loop, same registers)
+TRI = ("s32", "s33")
+ACC = "s[34:35]"
+SURVB, SURVB_LO, SURVB_HI = "s[24:25]", "s24", "s25"     # (CHG's registers: "some candidate was met in this leaf" is bit 30 of RF there)
+BIG = int(os.environ.get("RT_GEN_BATCH_MIN", "6"))       # leaves with at least so many triangles to test take the loop with four sets ...
+WORK0 = int(os.environ.get("RT_GEN_BATCH_WORK", "128"))  # ... once the wave has met so many triangles in such leaves (lane 60 of ST_FIRST counts them over
+                                                         # all walks of the wave): only a wave with a long life ahead waits for its records alone on its SIMD
+J = ("s20", "s21", "s22", "s23")
+RSET = (36, 52, 68, 84)
+RF = "vcc_lo"
+TMPP, TMP0, TMP1 = "s[30:31]", "s30", "s31"
+PARKED = list(range(68, 79)) + [82, 83]
 
 # ---- vector registers ----
 E_XY, EZ = "v[40:41]", "v42"
@@ -55,7 +76,7 @@ def scan_sorted():
     L = []
     # (scalar loads return out of order: before a record is requested into registers that an earlier request - the sibling
     #  behind the one that was accepted, the triangle behind a leaf's last - may still be on its way into, that one is awaited)
-    L += ["LT_enter_%=:",
+    L += ["LT_enter_%=:"] + (["s_add_u32 %s, %s, 1" % ("s15", "s15")] if os.environ.get("RT_GEN_COUNT") else []) + [
           "s_ff1_i32_b32 %s, %s" % (IDX, REM),
           "s_lshl_b32 %s, %s, 5" % (OFF, IDX),
           "s_waitcnt lgkmcnt(0)",
@@ -63,6 +84,8 @@ def scan_sorted():
           "LT_scan_%=:",
           "s_bitset0_b32 %s, %s" % (REM, IDX),
           "s_waitcnt lgkmcnt(0)"]
+    if os.environ.get("RT_GEN_COUNT"):
+        L.append("s_add_u32 %s, %s, 0x10000" % ("s14", "s14"))
     for i, (inv, fc) in enumerate(((IX, FCX), (IX, FCX), (IY, FCY), (IY, FCY), (IZ, FCZ), (IZ, FCZ))):
         L.append("v_fma_f32 %s, %s, %s, -%s" % (t[i], s(NX + i), inv, fc))
     L += ["s_mov_b32 %s, %s" % (RFIRST, s(NX + 6)),
@@ -87,7 +110,7 @@ def scan_sorted():
           "LT_pop_%=:",
           "s_cmp_eq_u32 m0, 0",
           "s_cbranch_scc1 LT_done_%=",
-          "s_add_u32 m0, m0, -1",
+          "s_add_u32 m0, m0, -1", "@COUNT_POP",
           "s_nop 1",
           "v_readlane_b32 %s, %s, m0" % (FIRST, ST_FIRST),
           "v_readlane_b32 %s, %s, m0" % (REM, ST_CUR),
@@ -101,7 +124,7 @@ def scan_sorted():
           "s_addc_u32 s69, %s, 0" % NODES[1],
           "s_branch LT_enter_%=",
           # ---- some ray of the branch may hit the child: margin and acceptance (rt_node_slab_tail_fused)
-          "LT_tail_%=:",
+          "LT_tail_%=:", "@COUNT_TAIL",
           "v_med3_f32 v76, %s, %s, %s" % (t[0], t[2], t[4]),
           "v_med3_f32 v77, %s, %s, %s" % (t[1], t[3], t[5]),
           "v_min3_f32 v78, %s, %s, %s" % (t[0], t[2], t[4]),
@@ -160,7 +183,7 @@ def scan_zero(pattern):
     mnmx = [("v70", "v71"), ("v72", "v73")]
     SQ = T64
     INALL = "s[98:99]"   # (NR is consumed before the tail needs this)
-    L = ["LT_enter_%=:",
+    L = ["LT_enter_%=:"] + (["s_add_u32 %s, %s, 1" % ("s15", "s15")] if os.environ.get("RT_GEN_COUNT") else []) + [
          "s_ff1_i32_b32 %s, %s" % (IDX, REM),
          "s_lshl_b32 %s, %s, 5" % (OFF, IDX),
          "s_waitcnt lgkmcnt(0)",
@@ -168,6 +191,8 @@ def scan_zero(pattern):
          "LT_scan_%=:",
          "s_bitset0_b32 %s, %s" % (REM, IDX),
          "s_waitcnt lgkmcnt(0)"]
+    if os.environ.get("RT_GEN_COUNT"):
+        L.append("s_add_u32 %s, %s, 0x10000" % ("s14", "s14"))
     for i in range(6):
         L.append("v_sub_f32 %s, %s, %s" % (d[i], s(NX + i), ev[i // 2]))
     L += ["v_mov_b32 %s, %s" % (side, s(NX)),
@@ -193,7 +218,7 @@ def scan_zero(pattern):
           "LT_pop_%=:",
           "s_cmp_eq_u32 m0, 0",
           "s_cbranch_scc1 LT_done_%=",
-          "s_add_u32 m0, m0, -1",
+          "s_add_u32 m0, m0, -1", "@COUNT_POP",
           "s_nop 1",
           "v_readlane_b32 %s, %s, m0" % (FIRST, ST_FIRST),
           "v_readlane_b32 %s, %s, m0" % (REM, ST_CUR),
@@ -206,7 +231,7 @@ def scan_zero(pattern):
           "s_add_u32 s68, %s, %s" % (NODES[0], OFF),
           "s_addc_u32 s69, %s, 0" % NODES[1],
           "s_branch LT_enter_%=",
-          "LT_tail_%=:",
+          "LT_tail_%=:", "@COUNT_TAIL",
           "s_mov_b64 %s, %s" % (UND, NR)]                       # N = mine & ~outside, kept while NR's registers hold `inside on every zero axis`
     for j, k in enumerate(Z):
         mn, mx = mnmx[j]
@@ -280,8 +305,13 @@ def scan_zero(pattern):
     return L
 
 
+def count_instr(tag):
+    """Measurement builds (RT_GEN_COUNT=1, -DRT_STAGE_COUNT): the counter registers are the compiler's, named as operands in rt_kernel_wave.hip."""
+    return COUNTERS[tag]
+
+
 def triangle(q, other, tag, cur, nxt, masked):
-    """The numerator stages on the record in s[q : q+15] (at offset `cur`); midway the next record to be tested (offset `nxt`) is
+    """The numerator stages on the record in s[q : q+15] (at offset `cur`); first the next record to be tested (offset `nxt`) is
     requested into s[other : other+15]: the one behind it (`cur` + 64) in a leaf walked from end to end, the one of the lowest bit
     left in SURV in a leaf whose triangles were put in front of the wave's bundle first (masked)."""
     bxy, bz = "v[68:69]", "v74"
@@ -289,6 +319,10 @@ def triangle(q, other, tag, cur, nxt, masked):
     det, nb, nbs, ng, nt, sg = "v32", "v33", "v34", "v35", "v36", "v39"
     L = ["LT_tri%s_%%=:" % tag,
          "s_waitcnt lgkmcnt(0)",
+         # (the request for the record behind this one goes out first: the whole test lies between it and the wait for it)
+         "@NEXT",
+         "s_load_dwordx16 s[%d:%d], s[%s:%s], %s" % (other, other + 15, TRI[0][1:], TRI[1][1:], nxt),
+         "@COUNT_TRI",
          # stage 1: determinant and beta numerator (triangle.cu:117-131), operations paired two to an instruction
          "v_pk_mul_f32 v[64:65], %s, %s" % (C_ZX, s2(q + 10)),                                  # e2.y c2.z , e2.z c2.x
          "v_pk_mul_f32 v[66:67], %s, %s neg_lo:[0,1] neg_hi:[0,1]" % (C_YZ, s2(q + 12)),       # -(e2.z c2.y) , -(e2.x c2.z)
@@ -301,8 +335,6 @@ def triangle(q, other, tag, cur, nxt, masked):
          "v_pk_mul_f32 v[78:79], %s, v[70:71]" % bxy,                                           # b.x m00 , b.y m10
          "v_add_f32 v76, v76, v77",
          "v_mul_f32 v77, %s, v75" % s(q + 6),                                                   # e1.z m20
-         "@NEXT",
-         "s_load_dwordx16 s[%d:%d], s[%s:%s], %s" % (other, other + 15, TRI[0][1:], TRI[1][1:], nxt),
          "v_add_f32 %s, v76, v77" % det,
          "v_add_f32 v78, v78, v79",
          "v_mul_f32 v79, v75, %s" % bz,                                                         # m20 b.z
@@ -314,6 +346,7 @@ def triangle(q, other, tag, cur, nxt, masked):
          "s_and_b64 %s, %s, %s" % (PASS, PASS, ACC),
          "s_cbranch_scc0 LT_end%s_%%=" % tag,
          # stage 2: gamma numerator
+         "@COUNT_S2",
          "v_mul_f32 v37, %s, %s" % (s(q + 6), C2Y),
          "v_mul_f32 v38, %s, %s" % (s(q + 5), C2Z),
          "v_sub_f32 v37, v37, v38",                                                              # m01
@@ -333,6 +366,7 @@ def triangle(q, other, tag, cur, nxt, masked):
          "s_and_b64 %s, %s, %s" % (PASS, PASS, T64),
          "s_cbranch_scc0 LT_end%s_%%=" % tag,
          # stage 3: t numerator from the record's e1 x e2; t > 0, and t clearly beyond the closest hit is rejected without dividing
+         "@COUNT_S3",
          "v_and_b32 %s, 0x80000000, %s" % (sg, det),
          "v_mul_f32 v37, %s, %s" % (s(q + 7), bx),
          "v_mul_f32 v38, %s, %s" % (s(q + 14), by),
@@ -361,6 +395,9 @@ def triangle(q, other, tag, cur, nxt, masked):
                      "s_lshl_b32 %s, %s, 6" % (nxt, JT)] if masked else ["s_add_u32 %s, %s, 0x40" % (nxt, cur)])
         elif line == "@RES":
             out.append("s_mov_b32 %s, %d" % (RES, 2 if masked else 3))     # (which of the two leaf loops to come back to)
+        elif line.startswith("@COUNT"):
+            if os.environ.get("RT_GEN_COUNT"):
+                out.append(count_instr(line))
         elif line == "@SAVE":
             out += ["v_writelane_b32 %s, s98, 62" % ST_FIRST, "v_writelane_b32 %s, s99, 63" % ST_FIRST] if masked else []
         else:
@@ -423,7 +460,7 @@ def cull():
 
 
 def leaf(with_cull):
-    L = ["LT_leaf_%=:",
+    L = ["LT_leaf_%=:", "@COUNT_LEAF",
          "s_and_b32 %s, %s, 0xff" % (TEND, RMETA),
          "s_cbranch_scc0 LT_next_%="]
     if with_cull:
@@ -439,6 +476,11 @@ def leaf_masked():
          "s_bitcmp1_b32 %s, 8" % RMETA,                              # RT_LEAF_ASK: the host found the leaf's triangles worth asking about
          "s_cbranch_scc0 LT_leaf_all_%="]
     L += cull()
+    if BATCH:
+        L += ["s_bcnt1_i32_b64 %s, %s" % (JT, SURV),
+              "s_cmp_ge_u32 %s, %d" % (JT, BIG),
+              "s_cbranch_scc1 LT_big_masked_%=",
+              "LT_small_masked_%=:"]
     L += ["s_bitset1_b64 %s, 63" % SURV,
           "s_mov_b64 %s, 0" % CHG,
           "@PRIO",
@@ -461,8 +503,12 @@ def leaf_masked():
 
 def leaf_all():
     """Without a bundle: every triangle of the leaf, one record after the other."""
-    L = ["LT_leaf_all_%=:",
-          "s_lshl_b32 %s, %s, 6" % (TCUR, RFIRST),
+    L = ["LT_leaf_all_%=:"]
+    if BATCH:
+        L += ["s_cmp_ge_u32 %s, %d" % (TEND, BIG),
+              "s_cbranch_scc1 LT_big_all_%=",
+              "LT_small_all_%=:"]
+    L += ["s_lshl_b32 %s, %s, 6" % (TCUR, RFIRST),
           "s_lshl_b32 %s, %s, 6" % (TEND, TEND),
           "s_add_u32 %s, %s, %s" % (TEND, TEND, TCUR),
           "s_mov_b64 %s, 0" % CHG,
@@ -480,6 +526,7 @@ def leaf_all():
           "s_cmp_eq_u64 %s, 0" % CHG,
           "s_cbranch_scc1 LT_next_%=",
           # some ray's closest hit moved: shadow rays that are now known to be occluded drop out (ray.cu:70)
+          "LT_leaf_changed_%=:",
           "v_cmp_le_f32 vcc, 0, %s" % STOP,
           "v_cmp_lt_f32_e64 %s, %s, %s" % (T64, T, STOP),
           "s_and_b64 %s, %s, vcc" % (T64, T64),
@@ -488,6 +535,153 @@ def leaf_all():
           "s_and_b64 %s, %s, %s" % (MINE, TMASK, LIVE),
           "s_cbranch_scc1 LT_next_%=",
           "s_branch LT_pop_%="]
+    return L
+
+
+
+def batch_issue(slot, tmp):
+    """The next triangle to test of the open leaf: its index into J[slot], its record on its way into record set `slot`."""
+    q = RSET[slot]
+    return ["s_ff1_i32_b64 %s, %s" % (J[slot], SURVB),
+            "s_bitset0_b64 %s, %s" % (SURVB, J[slot]),
+            "s_bitset1_b64 %s, 63" % SURVB,                                 # (the end marker stays: asked again it answers 63 again)
+            "s_add_u32 %s, %s, %s" % (tmp, J[slot], RF),
+            "s_lshl_b32 %s, %s, 6" % (tmp, tmp),                            # (bit 30 of RF leaves with the shift)
+            "s_load_dwordx16 s[%d:%d], s[%s:%s], %s" % (q, q + 15, TRI[0][1:], TRI[1][1:], tmp)]
+
+
+def batch_test(slot, pending):
+    """The three numerator stages on record set `slot`.  With candidates the walk leaves for the quotients: the records that
+    were requested and not tested yet (`pending`) go back into SURVB, which waits in lanes 62 / 63 of ST_FIRST with RF in lane 61."""
+    q = RSET[slot]
+    bxy, bz = "v[68:69]", "v74"
+    bx, by = "v68", "v69"
+    det, nb, nbs, ng, nt, sg = "v32", "v33", "v34", "v35", "v36", "v39"
+    tag = "%d" % slot
+    L = ["LT_t%s_%%=:" % tag,
+         "s_cmp_eq_u32 %s, 63" % J[slot],
+         "s_cbranch_scc1 LT_unpark_%=",
+         "@COUNT_TRI",
+         "v_pk_mul_f32 v[64:65], %s, %s" % (C_ZX, s2(q + 10)),
+         "v_pk_mul_f32 v[66:67], %s, %s neg_lo:[0,1] neg_hi:[0,1]" % (C_YZ, s2(q + 12)),
+         "v_pk_add_f32 %s, %s, %s neg_lo:[0,1] neg_hi:[0,1]" % (bxy, E_XY, s2(q + 0)),
+         "v_pk_add_f32 v[70:71], v[64:65], v[66:67]",
+         "v_pk_mul_f32 v[72:73], %s, %s" % (C_YX, s2(q + 8)),
+         "v_subrev_f32 %s, %s, %s" % (bz, s(q + 2), EZ),
+         "v_sub_f32 v75, v72, v73",
+         "v_pk_mul_f32 v[76:77], %s, v[70:71]" % s2(q + 4),
+         "v_pk_mul_f32 v[78:79], %s, v[70:71]" % bxy,
+         "v_add_f32 v76, v76, v77",
+         "v_mul_f32 v77, %s, v75" % s(q + 6),
+         "v_add_f32 %s, v76, v77" % det,
+         "v_add_f32 v78, v78, v79",
+         "v_mul_f32 v79, v75, %s" % bz,
+         "v_add_f32 %s, v78, v79" % nb,
+         "v_med3_f32 %s, %s, 0, %s" % (nbs, nb, det),
+         "v_cmp_eq_f32_e64 %s, %s, %s" % (PASS, nbs, nb),
+         "s_and_b64 %s, %s, %s" % (PASS, PASS, ACC),
+         "s_cbranch_scc0 LT_e%s_%%=" % tag,
+         "@COUNT_S2",
+         "v_mul_f32 v37, %s, %s" % (s(q + 6), C2Y),
+         "v_mul_f32 v38, %s, %s" % (s(q + 5), C2Z),
+         "v_sub_f32 v37, v37, v38",
+         "v_mul_f32 v38, %s, %s" % (s(q + 4), C2Z),
+         "v_mul_f32 %s, %s, %s" % (sg, s(q + 6), C2X),
+         "v_sub_f32 v38, v38, %s" % sg,
+         "v_mul_f32 %s, %s, %s" % (sg, s(q + 5), C2X),
+         "v_mul_f32 %s, %s, %s" % (ng, s(q + 4), C2Y),
+         "v_sub_f32 %s, %s, %s" % (sg, sg, ng),
+         "v_mul_f32 v37, v37, %s" % bx,
+         "v_mul_f32 v38, v38, %s" % by,
+         "v_add_f32 v37, v37, v38",
+         "v_mul_f32 v38, %s, %s" % (sg, bz),
+         "v_add_f32 %s, v37, v38" % ng,
+         "v_med3_f32 v38, %s, 0, %s" % (ng, det),
+         "v_cmp_eq_f32_e64 %s, v38, %s" % (T64, ng),
+         "s_and_b64 %s, %s, %s" % (PASS, PASS, T64),
+         "s_cbranch_scc0 LT_e%s_%%=" % tag,
+         "@COUNT_S3",
+         "v_and_b32 %s, 0x80000000, %s" % (sg, det),
+         "v_mul_f32 v37, %s, %s" % (s(q + 7), bx),
+         "v_mul_f32 v38, %s, %s" % (s(q + 14), by),
+         "v_add_f32 v37, v37, v38",
+         "v_mul_f32 v38, %s, %s" % (s(q + 15), bz),
+         "v_add_f32 %s, v37, v38" % nt,
+         "v_xor_b32 v38, %s, %s" % (sg, nt),
+         "v_mul_f32_e64 v37, %s, |%s|" % (T, det),
+         "v_mul_f32 v37, 0x3f800008, v37",
+         "v_cmp_lt_f32_e64 %s, 0, v38" % TMPP,
+         "v_cmp_ge_f32_e64 %s, v37, v38" % T64,
+         "s_and_b64 %s, %s, %s" % (T64, T64, TMPP),
+         "s_and_b64 %s, %s, %s" % (PASS, PASS, T64),
+         "s_cbranch_scc0 LT_e%s_%%=" % tag,
+         "s_mov_b32 %s, %s" % (RPRIM, s(q + 3))]
+    L += ["s_bitset1_b64 %s, %s" % (SURVB, J[j]) for j in pending]
+    L += ["v_writelane_b32 %s, %s, 62" % (ST_FIRST, SURVB_LO),
+          "v_writelane_b32 %s, %s, 63" % (ST_FIRST, SURVB_HI),
+          "v_writelane_b32 %s, %s, 61" % (ST_FIRST, RF),
+          "s_mov_b32 %s, 4" % RES,
+          "s_branch LT_out_%=",
+          "LT_e%s_%%=:" % tag]
+    return L
+
+
+def leaf_big(with_cull):
+    """The loop with four record sets.  Entered at LT_big (SURVB: the triangles to test, no marker yet) with nothing parked."""
+    def long_wave(count, back):
+        return ["v_readlane_b32 %s, %s, 60" % (TMP0, ST_FIRST),
+                "s_nop 0",
+                "s_add_u32 %s, %s, %s" % (TMP0, TMP0, count),
+                "v_writelane_b32 %s, %s, 60" % (ST_FIRST, TMP0),
+                "s_cmp_lt_u32 %s, %d" % (TMP0, WORK0),
+                "s_cbranch_scc1 %s" % back]
+    L = []
+    if with_cull:
+        L += ["LT_big_masked_%=:"] + long_wave(JT, "LT_small_masked_%=") + [
+              "s_mov_b64 %s, %s" % (SURVB, SURV),
+              "s_branch LT_big_%="]
+    L += ["LT_big_all_%=:"] + long_wave(TEND, "LT_small_all_%=") + [
+         "s_bfm_b64 %s, %s, 0" % (SURVB, TEND),
+         "LT_big_%=:",
+         "s_bitset1_b64 %s, 63" % SURVB,
+         "s_mov_b32 %s, %s" % (RF, RFIRST)]
+    L += ["v_writelane_b32 %s, s%d, %d" % (ST_CUR, r, 32 + i) for i, r in enumerate(PARKED)]
+    L += ["LT_big_start_%=:"]
+    L += batch_issue(0, TMP0) + batch_issue(1, TMP1)
+    L += ["LT_lp_%=:",
+          "s_waitcnt lgkmcnt(0)",
+          "s_lshl_b64 %s, %s, 1" % (TMPP, SURVB),                       # nothing but the end marker left: no further requests
+          "s_cbranch_scc0 LT_noq_%="]
+    L += batch_issue(2, TMP0) + batch_issue(3, TMP1)
+    L += ["LT_p0_%=:"]
+    L += batch_test(0, (1, 2, 3)) + batch_test(1, (2, 3))
+    L += ["s_waitcnt lgkmcnt(0)",
+          "s_lshl_b64 %s, %s, 1" % (TMPP, SURVB),
+          "s_cbranch_scc0 LT_nop_%="]
+    L += batch_issue(0, TMP0) + batch_issue(1, TMP1)
+    L += ["LT_q0_%=:"]
+    L += batch_test(2, (3, 0, 1)) + batch_test(3, (0, 1))
+    L += ["s_branch LT_lp_%=",
+          "LT_noq_%=:", "s_mov_b32 %s, 63" % J[2], "s_mov_b32 %s, 63" % J[3], "s_branch LT_p0_%=",
+          "LT_nop_%=:", "s_mov_b32 %s, 63" % J[0], "s_mov_b32 %s, 63" % J[1], "s_branch LT_q0_%=",
+          "LT_unpark_%=:",
+          "s_waitcnt lgkmcnt(0)"]                                        # (a record still on its way would land in the state that comes back now)
+    L += ["v_readlane_b32 s%d, %s, %d" % (r, ST_CUR, 32 + i) for i, r in enumerate(PARKED)]
+    L += ["s_nop 1",
+          "s_lshl_b32 %s, %s, 5" % (OFF, IDX),
+          "s_load_dwordx8 s[84:91], %s, %s" % (BLK, OFF),               # the sibling behind the leaf, whose record gave way
+          "s_bitcmp1_b32 %s, 30" % RF,
+          "s_cbranch_scc0 LT_next_%=",
+          "s_branch LT_leaf_changed_%=",
+          "LT_resume_big_%=:",
+          "v_readlane_b32 %s, %s, 62" % (SURVB_LO, ST_FIRST),
+          "v_readlane_b32 %s, %s, 63" % (SURVB_HI, ST_FIRST),
+          "v_readlane_b32 %s, %s, 61" % (RF, ST_FIRST),
+          "s_nop 1",
+          "s_bitset1_b32 %s, 30" % RF,
+          "s_lshl_b64 %s, %s, 1" % (TMPP, SURVB),
+          "s_cbranch_scc0 LT_unpark_%=",
+          "s_branch LT_big_start_%="]
     return L
 
 
@@ -500,8 +694,13 @@ def block(pattern, with_cull):
               "s_cbranch_scc1 LT_resume_finish_%="]
     L += ["s_cmp_eq_u32 %s, 3" % RES,
           "s_cbranch_scc1 LT_resume_finish_all_%="]
+    if BATCH:
+        L += ["s_cmp_eq_u32 %s, 4" % RES,
+              "s_cbranch_scc1 LT_resume_big_%="]
     L += scan_sorted() if pattern == 0 else scan_zero(pattern)
     L += leaf(with_cull)
+    if BATCH:
+        L += leaf_big(with_cull)
     L += [# ---- re-entries: the record of the next sibling is requested again (its registers were not kept outside)
           "LT_resume_exact_%=:",
           "s_lshl_b32 %s, %s, 5" % (OFF, IDX),
@@ -549,6 +748,9 @@ def statement(with_cull):
     return L
 
 
+COUNTERS = {"@COUNT_TRI": "s_add_u32 s14, s14, 1", "@COUNT_S2": "s_add_u32 s17, s17, 1", "@COUNT_S3": "s_add_u32 s17, s17, 0x10000", "@COUNT_POP": "s_add_u32 s16, s16, 0x10000", "@COUNT_TAIL": "s_add_u32 s16, s16, 1", "@COUNT_LEAF": "s_add_u32 s15, s15, 0x10000"}
+
+
 def emit(line):
     if line == "@PRIO":
         return 'RT_PRIO_STEP'
@@ -557,22 +759,35 @@ def emit(line):
 
 def main():
     out = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "raytracer_amd", "csrc", "rt_trace_asm.inc")
+    if len(sys.argv) > 1:
+        out = sys.argv[1]
     with open(out, "w") as f:
         f.write("// Generated by tools/gen_trace_asm.py - do not edit.  Register map and operands: rt_kernel_wave.hip (walk_asm, trace_wave).\n")
         f.write("// RT_TRACE_ASM_CULL: the walk with the bundle test in front of a leaf's triangles (operands %[b0] .. %[b9], s19);\n")
         f.write("// RT_TRACE_ASM_PLAIN: the walk that tests every triangle of every leaf it enters (kernels whose rays never form a bundle).\n")
         f.write("// In both, one copy per kind of node test: rays that agree on their direction signs (s18 = 0), rays that share a zero pattern (s18 = 1 .. 6, bit k: component k is zero).\n")
-        # Measurement builds (-DRT_WALK_PRIO=k): a wave counts the leaves it enters (s23, zeroed by the caller) and raises its issue
+        # Measurement builds (-DRT_WALK_PRIO=k): a wave counts the leaves it enters (s17, zeroed by the caller) and raises its issue
         # priority after 2^k, 2^(k+1) and 2^(k+2) of them (a branch over one instruction is written as its offset, not a label).
         f.write("#ifdef RT_WALK_PRIO\n#define RT_PRIO_STR2(x) #x\n#define RT_PRIO_STR(x) RT_PRIO_STR2(x)\n"
-                "#define RT_PRIO_STEP \"s_add_u32 s23, s23, 1\\n\" \\\n"
-                "  \"s_bitcmp1_b32 s23, \" RT_PRIO_STR(RT_WALK_PRIO) \"\\n\" \"s_cbranch_scc0 1\\n\" \"s_setprio 1\\n\" \\\n"
-                "  \"s_bitcmp1_b32 s23, \" RT_PRIO_STR(RT_WALK_PRIO) \"+1\\n\" \"s_cbranch_scc0 1\\n\" \"s_setprio 2\\n\" \\\n"
-                "  \"s_bitcmp1_b32 s23, \" RT_PRIO_STR(RT_WALK_PRIO) \"+2\\n\" \"s_cbranch_scc0 1\\n\" \"s_setprio 3\\n\"\n"
+                "#define RT_PRIO_STEP \"s_add_u32 s17, s17, 1\\n\" \\\n"
+                "  \"s_bitcmp1_b32 s17, \" RT_PRIO_STR(RT_WALK_PRIO) \"\\n\" \"s_cbranch_scc0 1\\n\" \"s_setprio 1\\n\" \\\n"
+                "  \"s_bitcmp1_b32 s17, \" RT_PRIO_STR(RT_WALK_PRIO) \"+1\\n\" \"s_cbranch_scc0 1\\n\" \"s_setprio 2\\n\" \\\n"
+                "  \"s_bitcmp1_b32 s17, \" RT_PRIO_STR(RT_WALK_PRIO) \"+2\\n\" \"s_cbranch_scc0 1\\n\" \"s_setprio 3\\n\"\n"
                 "#else\n#define RT_PRIO_STEP \"\"\n#endif\n")
         for name, with_cull in (("RT_TRACE_ASM_CULL", True), ("RT_TRACE_ASM_PLAIN", False)):
             f.write("#define %s \\\n" % name)
-            f.write(" \\\n".join(emit(line) for line in statement(with_cull)))
+            if os.environ.get("RT_GEN_NOLOAD"):
+                body = statement(with_cull)
+                keep = []
+                for i, l in enumerate(body):
+                    prev = body[i - 1] if i else ""
+                    in_loop = ("s_load_dwordx16" in l and ("s_add_u32" in prev or "s_lshl_b32 s2" in prev))   # (only the triangle loops: without the siblings' records the scan would descend into the same child again and again)
+                    keep.append("s_nop 0" if in_loop else l)
+                statement_lines = keep
+            else:
+                statement_lines = statement(with_cull)
+            lines = [(count_instr(l) if l in COUNTERS else l) if os.environ.get("RT_GEN_COUNT") else l for l in statement_lines if os.environ.get("RT_GEN_COUNT") or l not in COUNTERS]
+            f.write(" \\\n".join(emit(line) for line in lines))
             f.write("\n")
     print("wrote", os.path.normpath(out))
 
