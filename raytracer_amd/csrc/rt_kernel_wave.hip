@@ -57,14 +57,6 @@ __device__ __forceinline__ uint32_t uni(uint32_t v) { return __builtin_amdgcn_re
 #define RT_PATHS_ON false
 #endif
 
-// Measurement builds (-DRT_WALK_PRIO=k): the wave's count of leaves entered travels from render_wave down to the assembly walk.
-#ifdef RT_WALK_PRIO
-#define RT_WORK_PARAM , uint32_t& rt_walk_work
-#define RT_WORK_ARG , rt_walk_work
-#else
-#define RT_WORK_PARAM
-#define RT_WORK_ARG
-#endif
 
 // Minimum of a value over the 64 lanes, the same in every lane (all lanes active): quad swaps and row mirrors, then the
 // four rows through scalar registers.
@@ -147,7 +139,7 @@ __device__ float* rt_dbg_ts();   // the `t` output of the launch (defined behind
 template <bool CULL>
 __device__ __forceinline__ uint64_t walk_asm(const float4* nodes, uint32_t variant, uint32_t zpat, const float4* tri_leaf, uint32_t top_first, uint32_t rem,
                                              uint64_t live, const RtVec3& e, const RtVec3& d, const RtVec3& inv, const RtVec3& fc, float neg_eb,
-                                             float stop_t, Hit& hit, WaveStack& st, float* bary_lds, uint32_t cull, const RtBundle& bundle RT_WORK_PARAM) {
+                                             float stop_t, Hit& hit, WaveStack& st, float* bary_lds, uint32_t cull, const RtBundle& bundle) {
   const RtVec3 c2 = {-d.x, -d.y, -d.z};
   // (wave-uniform values, pinned to scalar registers once: the walk reads them on every leaf it enters)
   const uint32_t b0 = uni(__float_as_uint(bundle.ox)), b1 = uni(__float_as_uint(bundle.oy)), b2 = uni(__float_as_uint(bundle.oz)), b3 = uni(__float_as_uint(bundle.ax)),
@@ -161,22 +153,20 @@ __device__ __forceinline__ uint64_t walk_asm(const float4* nodes, uint32_t varia
   // (the loop with four record sets parks s[68:83] while its leaf is open and may leave for the quotients with records in
   //  them: the node array's address is an operand that comes back changed, like the rest of that range)
   uint64_t a_nodes = (uint64_t)(uintptr_t)nodes;
+  uint32_t a_work = 0u;   // triangles met in large leaves so far: the block treats a walk with many of them differently (see the register map at the call)
   const float cmax = rt_max3(fabsf(fc.x), fabsf(fc.y), fabsf(fc.z));
   float a_det = 0.f, a_nb = 0.f, a_ng = 0.f, a_nt = 0.f;
 #ifdef RT_WAVE_TIMES_CLK
   uint32_t dbg_n1 = 0u, dbg_n2 = 0u; unsigned long long dbg_out = 0ull;
 #endif
-#ifdef RT_WALK_PRIO
-  uint32_t a_work = uni(rt_walk_work);   // measurement builds: leaves entered by the wave so far, over all its walks (see RT_PRIO_STEP in rt_trace_asm.inc)
-#define RT_PRIO_OPERAND , "+{s17}"(a_work)
-#elif defined(RT_STAGE_COUNT)
+#ifdef RT_STAGE_COUNT
   // measurement builds (with -DRT_WAVE_TIMES_CLK and a block generated with RT_GEN_COUNT=1): s17 counts the triangle iterations
   // that went on to the second (low half) and third stage (high half), s14 the triangle (low half) and node iterations (high half)
   // s15 the blocks of children entered (low half) and the leaves (high half), s16 the children that came to the margin test (low half) and the pops
   uint32_t a_stage = 0u, a_iter = 0u, a_enter = 0u, a_tail = 0u;
-#define RT_PRIO_OPERAND , "+{s17}"(a_stage), "+{s14}"(a_iter), "+{s15}"(a_enter), "+{s16}"(a_tail)
+#define RT_COUNT_OPERAND , "+{s17}"(a_stage), "+{s14}"(a_iter), "+{s15}"(a_enter), "+{s16}"(a_tail)
 #else
-#define RT_PRIO_OPERAND
+#define RT_COUNT_OPERAND
 #endif
   // (one copy of the block per kind of node test inside the one statement: sign-uniform rays (0), or the rays' common
   //  zero pattern (1..6), chosen by s18)
@@ -185,14 +175,14 @@ __device__ __forceinline__ uint64_t walk_asm(const float4* nodes, uint32_t varia
       asm volatile(RT_TRACE_ASM_CULL
           : "+{s[68:69]}"(a_blk), "+{s70}"(a_rem), "+{s71}"(a_first), "+{s[72:73]}"(a_tmask), "+{s[74:75]}"(a_mine), "+{s[76:77]}"(a_live),
             "+{s78}"(a_idx), "+{s79}"(a_rfirst), "+{s80}"(a_rmeta), "+{s[34:35]}"(a_acc), "+{s[96:97]}"(a_und), "+{s[28:29]}"(a_pass),
-            "+{s20}"(a_tcur), "+{s22}"(a_tend), "+{s[24:25]}"(a_chg), "+{s30}"(a_res), "+{s31}"(a_prim), "+{m0}"(a_sp) RT_PRIO_OPERAND,
+            "+{s20}"(a_tcur), "+{s22}"(a_tend), "+{s[24:25]}"(a_chg), "+{s30}"(a_res), "+{s31}"(a_prim), "+{m0}"(a_sp) RT_COUNT_OPERAND,
             "+{v60}"(st.first), "+{v61}"(st.cur), "+{v62}"(st.mask_lo), "+{v63}"(st.mask_hi),
-            "={v32}"(a_det), "={v33}"(a_nb), "={v35}"(a_ng), "={v36}"(a_nt), "+{s[82:83]}"(a_nodes)
+            "={v32}"(a_det), "={v33}"(a_nb), "={v35}"(a_ng), "={v36}"(a_nt), "+{s[82:83]}"(a_nodes), "+{s23}"(a_work)
           : "{s[32:33]}"(a_tri), "{s18}"(zpat), "{s19}"(cull), "{v[40:41]}"(e_xy), "{v42}"(e.z), "{v[44:45]}"(c_zx), "{v[46:47]}"(c_yz),
             "{v[48:49]}"(c_yx), "{v50}"(inv.x), "{v51}"(inv.y), "{v52}"(inv.z), "{v53}"(fc.x), "{v54}"(fc.y), "{v55}"(fc.z), "{v56}"(cmax),
             "{v57}"(neg_eb), "{v58}"(hit.t), "{v59}"(stop_t),
             [b0] "s"(b0), [b1] "s"(b1), [b2] "s"(b2), [b3] "s"(b3), [b4] "s"(b4), [b5] "s"(b5), [b6] "s"(b6), [b7] "s"(b7), [b8] "s"(b8), [b9] "s"(b9)
-          : "s23", "s92", "s93", "s94", "s95", "s36", "s37", "s38", "s39", "s40", "s41", "s42", "s43", "s44", "s45", "s46", "s47", "s48", "s49", "s50", "s51", "s52", "s53", "s54", "s55",
+          : "s92", "s93", "s94", "s95", "s36", "s37", "s38", "s39", "s40", "s41", "s42", "s43", "s44", "s45", "s46", "s47", "s48", "s49", "s50", "s51", "s52", "s53", "s54", "s55",
             "s56", "s57", "s58", "s59", "s60", "s61", "s62", "s63", "s64", "s65", "s66", "s67", "s81", "s84", "s85", "s86", "s87", "s88", "s89", "s90",
             "s91", "s98", "s99", "s26", "s27", "s21", "v34", "v37", "v38", "v39", "v64", "v65", "v66", "v67", "v68", "v69", "v70", "v71", "v72", "v73", "v74",
             "v75", "v76", "v77", "v78", "v79", "vcc", "scc");
@@ -200,13 +190,13 @@ __device__ __forceinline__ uint64_t walk_asm(const float4* nodes, uint32_t varia
       asm volatile(RT_TRACE_ASM_PLAIN
           : "+{s[68:69]}"(a_blk), "+{s70}"(a_rem), "+{s71}"(a_first), "+{s[72:73]}"(a_tmask), "+{s[74:75]}"(a_mine), "+{s[76:77]}"(a_live),
             "+{s78}"(a_idx), "+{s79}"(a_rfirst), "+{s80}"(a_rmeta), "+{s[34:35]}"(a_acc), "+{s[96:97]}"(a_und), "+{s[28:29]}"(a_pass),
-            "+{s20}"(a_tcur), "+{s22}"(a_tend), "+{s[24:25]}"(a_chg), "+{s30}"(a_res), "+{s31}"(a_prim), "+{m0}"(a_sp) RT_PRIO_OPERAND,
+            "+{s20}"(a_tcur), "+{s22}"(a_tend), "+{s[24:25]}"(a_chg), "+{s30}"(a_res), "+{s31}"(a_prim), "+{m0}"(a_sp) RT_COUNT_OPERAND,
             "+{v60}"(st.first), "+{v61}"(st.cur), "+{v62}"(st.mask_lo), "+{v63}"(st.mask_hi),
-            "={v32}"(a_det), "={v33}"(a_nb), "={v35}"(a_ng), "={v36}"(a_nt), "+{s[82:83]}"(a_nodes)
+            "={v32}"(a_det), "={v33}"(a_nb), "={v35}"(a_ng), "={v36}"(a_nt), "+{s[82:83]}"(a_nodes), "+{s23}"(a_work)
           : "{s[32:33]}"(a_tri), "{s18}"(zpat), "{v[40:41]}"(e_xy), "{v42}"(e.z), "{v[44:45]}"(c_zx), "{v[46:47]}"(c_yz),
             "{v[48:49]}"(c_yx), "{v50}"(inv.x), "{v51}"(inv.y), "{v52}"(inv.z), "{v53}"(fc.x), "{v54}"(fc.y), "{v55}"(fc.z), "{v56}"(cmax),
             "{v57}"(neg_eb), "{v58}"(hit.t), "{v59}"(stop_t)
-          : "s23", "s92", "s93", "s94", "s95", "s36", "s37", "s38", "s39", "s40", "s41", "s42", "s43", "s44", "s45", "s46", "s47", "s48", "s49", "s50", "s51", "s52", "s53", "s54", "s55",
+          : "s92", "s93", "s94", "s95", "s36", "s37", "s38", "s39", "s40", "s41", "s42", "s43", "s44", "s45", "s46", "s47", "s48", "s49", "s50", "s51", "s52", "s53", "s54", "s55",
             "s56", "s57", "s58", "s59", "s60", "s61", "s62", "s63", "s64", "s65", "s66", "s67", "s81", "s84", "s85", "s86", "s87", "s88", "s89", "s90",
             "s91", "s98", "s99", "s26", "s27", "s21", "v34", "v37", "v38", "v39", "v64", "v65", "v66", "v67", "v68", "v69", "v70", "v71", "v72", "v73", "v74",
             "v75", "v76", "v77", "v78", "v79", "vcc", "scc");
@@ -269,9 +259,6 @@ __device__ __forceinline__ uint64_t walk_asm(const float4* nodes, uint32_t varia
     }
   }
 #endif
-#ifdef RT_WALK_PRIO
-  rt_walk_work = a_work;
-#endif
   return a_live;
 }
 
@@ -283,7 +270,7 @@ template <bool COUNT, bool CULLABLE>
 __device__ __forceinline__ void trace_wave(const float4* __restrict__ nodes, int n_wnodes, const float4* __restrict__ tri_leaf,
                                            const RtSphere* __restrict__ spheres, int n_spheres, bool has_oct, bool want,
                                            const RtVec3& e, const RtVec3& d, float stop_t, Hit& hit, WaveStack& st,
-                                           int lane, Tally& tl, float* cull_lds, uint32_t cull_offset, float cull_r0_max, float cull_ksp_max RT_WORK_PARAM) {
+                                           int lane, Tally& tl, float* cull_lds, uint32_t cull_offset, float cull_r0_max, float cull_ksp_max) {
   // Lane sets are kept as wave-uniform 64-bit masks in SGPRs (who still has an undecided ray, who entered the
   // current branch, who accepted the current node, ...); they are combined on the scalar unit and only turned
   // back into a per-lane predicate on the rare paths that need one.
@@ -409,16 +396,16 @@ __device__ __forceinline__ void trace_wave(const float4* __restrict__ nodes, int
     // (origin, negated direction in the pairs the first stage multiplies, inverse direction, e * inv, margin terms,
     // closest hit so far, shadow-ray length), v[60:63] the wave's stack, v32 v33 v35 v36 determinant and numerators
     // of a candidate, v34 v37:v39 v64:v79 scratch.
-    // A wave with a long life - one that has met 128 triangles in leaves with six or more to test; lane 60 of v60 counts them
-    // over all its walks - takes such leaves through a loop with FOUR record sets (re-entry 4): s[68:83] and s[84:99] hold
-    // records too, the traversal state that lives there waits in lanes 32 .. 44 of v61, s20 .. s23 are the leaf-relative
-    // indices of the records in the four sets, s[24:25] the triangles still to request, vcc_lo the leaf's first record
-    // (outside the block: lane 61 of v60).  Two records are tested while the next two are on their way: a scalar load
+    // A walk with a long life ahead - one that has met 64 triangles in leaves with six or more to test; s23 counts them -
+    // takes such leaves through a loop with FOUR record sets (re-entry 4): s[68:83] and s[84:99] hold records too, the
+    // traversal state that lives there waits in lanes 32 .. 44 of v61, s20 .. s23 are the leaf-relative indices of the
+    // records in the four sets, s[24:25] the triangles still to request, vcc_lo the leaf's first record (outside the
+    // block: lane 61 of v60).  Two records are tested while the next two are on their way: a scalar load
     // takes such a wave about 400 cycles, a test 150, loads return out of order and the only wait is for all of them.
     if ((presorted || zpat != 0u) && FUSED && (rem & 0xffu) != 0u) {
       RtBundle bundle = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
       const uint32_t cull = (CULLABLE && cull_offset != 0u && wave_bundle(live, e, d, stop_t, bundle, cull_r0_max, cull_ksp_max)) ? cull_offset : 0u;
-      live = walk_asm<CULLABLE>(nodes, variant, zpat, tri_leaf, top_first, rem, live, e, d, inv, fc, neg_eb, stop_t, hit, st, nullptr, cull, bundle RT_WORK_ARG);
+      live = walk_asm<CULLABLE>(nodes, variant, zpat, tri_leaf, top_first, rem, live, e, d, inv, fc, neg_eb, stop_t, hit, st, nullptr, cull, bundle);
       if (!live) return;
     } else {
 #endif
@@ -882,7 +869,7 @@ template <bool CULLABLE>
 __device__ __forceinline__ uint64_t trace_class(const float4* __restrict__ nodes, int n_wnodes, const float4* __restrict__ tri_leaf,
                                                 const RtSphere* __restrict__ spheres, int n_spheres, bool has_oct, bool want,
                                                 const RtVec3& e, const RtVec3& d, float stop_t, Hit& hit, WaveStack& st, float* bary_lds,
-                                                uint32_t cull_offset, float cull_r0_max, float cull_ksp_max RT_WORK_PARAM) {
+                                                uint32_t cull_offset, float cull_r0_max, float cull_ksp_max) {
   const uint64_t pending = __builtin_amdgcn_ballot_w64(want);
   if (!pending) return 0ull;
   uint64_t cls = pending, after = pending;
@@ -913,7 +900,7 @@ __device__ __forceinline__ uint64_t trace_class(const float4* __restrict__ nodes
       }
       RtBundle bundle = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
       const uint32_t cull = (CULLABLE && cull_offset != 0u && wave_bundle(cls, e, d, stop_t, bundle, cull_r0_max, cull_ksp_max)) ? cull_offset : 0u;
-      after = walk_asm<CULLABLE>(vnodes, variant, zpat, tri_leaf, top_first, rem, cls, e, d, inv, fu.c, neg_eb, stop_t, hit, st, bary_lds, cull, bundle RT_WORK_ARG);
+      after = walk_asm<CULLABLE>(vnodes, variant, zpat, tri_leaf, top_first, rem, cls, e, d, inv, fu.c, neg_eb, stop_t, hit, st, bary_lds, cull, bundle);
     }
   }
   if (n_spheres > 0 && after) {
@@ -1161,9 +1148,6 @@ __global__ __launch_bounds__(RT_WBLOCK, !MESH ? (BOUNCE ? RT_WAVES_PER_SIMD_SPHE
   auto count = [&](int which) { __hip_atomic_fetch_add(MY_COUNTS() + which * RT_WBLOCK, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); };
   __shared__ float cull_sh[16 * (RT_WBLOCK / 64)];   // bounds of the wave's rays during a walk (trace_wave)
   WaveStack st = {0u, 0u, 0u, 0u};
-#ifdef RT_WALK_PRIO
-  uint32_t rt_walk_work = 0u;
-#endif
   // Pixel of a thread: wave w of the block owns the 8x8 tile (w % RT_WAVES_X, w / RT_WAVES_X) of the block's pixels.  The
   // coordinates are needed at the start, after the primary ray and at the end; they are derived again each time
   // from an opaque copy of the thread index, so that none of them occupies a register (or a spill slot) in between.
@@ -1372,11 +1356,11 @@ __global__ __launch_bounds__(RT_WBLOCK, !MESH ? (BOUNCE ? RT_WAVES_PER_SIMD_SPHE
       if (LANES) trace_lanes(nodes, LATE(node_skip), tri_leaf, spheres, n_spheres, has_oct != 0, want, tr_e, tr_d, stop_t, h);
       else if (CLASSES) {
         float* const bary = parked + (SW + 4) * RT_WBLOCK + (RT_WBLOCK == 64 ? 0 : (TID() & ~63));   // the wave's columns of the two barycentric words
-        traced = in_mask(trace_class<!queued>(nodes, n_wnodes, tri_leaf, spheres, n_spheres, has_oct != 0, want, tr_e, tr_d, stop_t, h, st, bary, LATE(cull_offset), LATE(cull_r0_max), LATE(cull_ksp_max) RT_WORK_ARG));
+        traced = in_mask(trace_class<!queued>(nodes, n_wnodes, tri_leaf, spheres, n_spheres, has_oct != 0, want, tr_e, tr_d, stop_t, h, st, bary, LATE(cull_offset), LATE(cull_r0_max), LATE(cull_ksp_max)));
         asm volatile("" ::: "memory");
         h.bet = bary[LANE()]; h.gam = bary[RT_WBLOCK + LANE()];   // (only meaningful, and only used, when a triangle was hit)
       }
-      else trace_wave<COUNT, !queued && !COUNT>(nodes, n_wnodes, tri_leaf, spheres, n_spheres, has_oct != 0, want, tr_e, tr_d, stop_t, h, st, LANE(), tl, cull_sh + 16 * (TID() >> 6), COUNT ? 0u : LATE(cull_offset), LATE(cull_r0_max), LATE(cull_ksp_max) RT_WORK_ARG);
+      else trace_wave<COUNT, !queued && !COUNT>(nodes, n_wnodes, tri_leaf, spheres, n_spheres, has_oct != 0, want, tr_e, tr_d, stop_t, h, st, LANE(), tl, cull_sh + 16 * (TID() >> 6), COUNT ? 0u : LATE(cull_offset), LATE(cull_r0_max), LATE(cull_ksp_max));
       asm volatile("" ::: "memory");
       unpark<BOUNCE, TEX, QPRIMARY>(sh, MY_PARK());
       }

@@ -46,8 +46,8 @@ TRI = ("s32", "s33")
 ACC = "s[34:35]"
 SURVB, SURVB_LO, SURVB_HI = "s[24:25]", "s24", "s25"     # (CHG's registers: "some candidate was met in this leaf" is bit 30 of RF there)
 BIG = int(os.environ.get("RT_GEN_BATCH_MIN", "6"))       # leaves with at least so many triangles to test take the loop with four sets ...
-WORK0 = int(os.environ.get("RT_GEN_BATCH_WORK", "128"))  # ... once the wave has met so many triangles in such leaves (lane 60 of ST_FIRST counts them over
-                                                         # all walks of the wave): only a wave with a long life ahead waits for its records alone on its SIMD
+WORK0 = int(os.environ.get("RT_GEN_BATCH_WORK", "64"))  # ... once the walk has met so many triangles in such leaves (WORK counts them): only
+                                                         # a wave with a long life ahead waits for its records alone on its SIMD
 J = ("s20", "s21", "s22", "s23")
 RSET = (36, 52, 68, 84)
 RF = "vcc_lo"
@@ -60,6 +60,10 @@ C_ZX, C_YZ, C_YX = "v[44:45]", "v[46:47]", "v[48:49]"
 C2X, C2Y, C2Z = "v45", "v46", "v44"
 IX, IY, IZ, FCX, FCY, FCZ, CMAX, NEB, T, STOP = "v50", "v51", "v52", "v53", "v54", "v55", "v56", "v57", "v58", "v59"
 ST_FIRST, ST_CUR, ST_LO, ST_HI = "v60", "v61", "v62", "v63"
+
+
+WORK = "s23"                      # triangles the walk has met in leaves with BIG or more to test (an operand, zero when the walk starts; inside the
+                                  # loop with four sets the register is J[3], and WORK0 again behind it)
 
 
 def s(n):
@@ -629,11 +633,8 @@ def batch_test(slot, pending):
 def leaf_big(with_cull):
     """The loop with four record sets.  Entered at LT_big (SURVB: the triangles to test, no marker yet) with nothing parked."""
     def long_wave(count, back):
-        return ["v_readlane_b32 %s, %s, 60" % (TMP0, ST_FIRST),
-                "s_nop 0",
-                "s_add_u32 %s, %s, %s" % (TMP0, TMP0, count),
-                "v_writelane_b32 %s, %s, 60" % (ST_FIRST, TMP0),
-                "s_cmp_lt_u32 %s, %d" % (TMP0, WORK0),
+        return ["s_add_u32 %s, %s, %s" % (WORK, WORK, count),
+                "s_cmp_lt_u32 %s, %d" % (WORK, WORK0),
                 "s_cbranch_scc1 %s" % back]
     L = []
     if with_cull:
@@ -668,6 +669,7 @@ def leaf_big(with_cull):
           "s_waitcnt lgkmcnt(0)"]                                        # (a record still on its way would land in the state that comes back now)
     L += ["v_readlane_b32 s%d, %s, %d" % (r, ST_CUR, 32 + i) for i, r in enumerate(PARKED)]
     L += ["s_nop 1",
+          "s_mov_b32 %s, %d" % (WORK, WORK0),                            # (J[3]'s register: the walk stays one with a long life)
           "s_lshl_b32 %s, %s, 5" % (OFF, IDX),
           "s_load_dwordx8 s[84:91], %s, %s" % (BLK, OFF),               # the sibling behind the leaf, whose record gave way
           "s_bitcmp1_b32 %s, 30" % RF,
@@ -752,8 +754,6 @@ COUNTERS = {"@COUNT_TRI": "s_add_u32 s14, s14, 1", "@COUNT_S2": "s_add_u32 s17, 
 
 
 def emit(line):
-    if line == "@PRIO":
-        return 'RT_PRIO_STEP'
     return '"%s\\n"' % line
 
 
@@ -766,14 +766,6 @@ def main():
         f.write("// RT_TRACE_ASM_CULL: the walk with the bundle test in front of a leaf's triangles (operands %[b0] .. %[b9], s19);\n")
         f.write("// RT_TRACE_ASM_PLAIN: the walk that tests every triangle of every leaf it enters (kernels whose rays never form a bundle).\n")
         f.write("// In both, one copy per kind of node test: rays that agree on their direction signs (s18 = 0), rays that share a zero pattern (s18 = 1 .. 6, bit k: component k is zero).\n")
-        # Measurement builds (-DRT_WALK_PRIO=k): a wave counts the leaves it enters (s17, zeroed by the caller) and raises its issue
-        # priority after 2^k, 2^(k+1) and 2^(k+2) of them (a branch over one instruction is written as its offset, not a label).
-        f.write("#ifdef RT_WALK_PRIO\n#define RT_PRIO_STR2(x) #x\n#define RT_PRIO_STR(x) RT_PRIO_STR2(x)\n"
-                "#define RT_PRIO_STEP \"s_add_u32 s17, s17, 1\\n\" \\\n"
-                "  \"s_bitcmp1_b32 s17, \" RT_PRIO_STR(RT_WALK_PRIO) \"\\n\" \"s_cbranch_scc0 1\\n\" \"s_setprio 1\\n\" \\\n"
-                "  \"s_bitcmp1_b32 s17, \" RT_PRIO_STR(RT_WALK_PRIO) \"+1\\n\" \"s_cbranch_scc0 1\\n\" \"s_setprio 2\\n\" \\\n"
-                "  \"s_bitcmp1_b32 s17, \" RT_PRIO_STR(RT_WALK_PRIO) \"+2\\n\" \"s_cbranch_scc0 1\\n\" \"s_setprio 3\\n\"\n"
-                "#else\n#define RT_PRIO_STEP \"\"\n#endif\n")
         for name, with_cull in (("RT_TRACE_ASM_CULL", True), ("RT_TRACE_ASM_PLAIN", False)):
             f.write("#define %s \\\n" % name)
             if os.environ.get("RT_GEN_NOLOAD"):
@@ -786,7 +778,7 @@ def main():
                 statement_lines = keep
             else:
                 statement_lines = statement(with_cull)
-            lines = [(count_instr(l) if l in COUNTERS else l) if os.environ.get("RT_GEN_COUNT") else l for l in statement_lines if os.environ.get("RT_GEN_COUNT") or l not in COUNTERS]
+            lines = [(count_instr(l) if l in COUNTERS else l) if os.environ.get("RT_GEN_COUNT") else l for l in statement_lines if l != "@PRIO" and (os.environ.get("RT_GEN_COUNT") or l not in COUNTERS)]
             f.write(" \\\n".join(emit(line) for line in lines))
             f.write("\n")
     print("wrote", os.path.normpath(out))
