@@ -688,17 +688,20 @@ def leaf_big(with_cull):
 
 
 def block(pattern, with_cull):
+    # (a walk that starts is the most frequent way in; of the re-entries a wave with a long life makes most behind candidates
+    #  of the loop with four sets: a compare and a branch not taken cost a lone wave 24 cycles)
     L = ["s_waitcnt lgkmcnt(0)",
-         "s_cmp_eq_u32 %s, 1" % RES,
-         "s_cbranch_scc1 LT_resume_exact_%="]
-    if with_cull:
-        L += ["s_cmp_eq_u32 %s, 2" % RES,
-              "s_cbranch_scc1 LT_resume_finish_%="]
-    L += ["s_cmp_eq_u32 %s, 3" % RES,
-          "s_cbranch_scc1 LT_resume_finish_all_%="]
+         "s_cmp_eq_u32 %s, 0" % RES,
+         "s_cbranch_scc1 LT_enter_%="]
     if BATCH:
         L += ["s_cmp_eq_u32 %s, 4" % RES,
               "s_cbranch_scc1 LT_resume_big_%="]
+    L += ["s_cmp_eq_u32 %s, 1" % RES,
+          "s_cbranch_scc1 LT_resume_exact_%="]
+    if with_cull:
+        L += ["s_cmp_eq_u32 %s, 2" % RES,
+              "s_cbranch_scc1 LT_resume_finish_%="]
+    L += ["s_branch LT_resume_finish_all_%="]
     L += scan_sorted() if pattern == 0 else scan_zero(pattern)
     L += leaf(with_cull)
     if BATCH:
@@ -739,9 +742,10 @@ def block(pattern, with_cull):
 def statement(with_cull):
     # ONE assembly statement with the seven copies behind a dispatch on the pattern (s18): several statements in a
     # switch would have the compiler merge their scalar outputs through values it no longer knows to be wave-uniform
-    L = []
-    for pattern in range(1, 7):
+    L = ["s_cmp_eq_u32 s18, 0", "s_cbranch_scc1 LT0_begin_%="]       # (nearly every walk)
+    for pattern in range(1, 6):
         L += ["s_cmp_eq_u32 s18, %d" % pattern, "s_cbranch_scc1 LT%d_begin_%%=" % pattern]
+    L += ["s_branch LT6_begin_%="]
     for pattern in range(7):
         B = ["LT%d_begin_%%=:" % pattern] + block(pattern, with_cull) + ["s_branch LT_end_all_%="]
         L += [line.replace("LT_", "LT%d_" % pattern) if "LT_end_all" not in line else line for line in B]
