@@ -11,8 +11,12 @@ HIPFLAGS  := -std=c++17 -O3 -ffp-contract=off -fPIC --offload-arch=$(ARCH) -Wall
 
 LIB := raytracer_amd/librt_amd.so
 RUN := raytracer_amd/run
+# The same library with the leaf loop of long-lived waves (four triangle records in flight, tools/gen_trace_asm.py) forced on
+# every leaf of every wave: production takes that loop for few leaves of few waves, the parity tests run against this build
+# too (tests/test_stress_variant.py) so that every scene walks through it.
+STRESS := raytracer_amd/librt_amd_stress.so
 
-all: $(LIB) $(RUN) oracle
+all: $(LIB) $(RUN) $(STRESS) oracle
 
 $(CSRC)/rt_host.o: $(CSRC)/rt_host.cpp $(CSRC)/rt_internal.h include/rt_amd.h
 	$(CXX) $(HOSTFLAGS) -c $< -o $@
@@ -27,6 +31,18 @@ $(CSRC)/%.o: $(CSRC)/%.hip $(CSRC)/rt_kernels.h $(CSRC)/rt_internal.h $(CSRC)/rt
 $(LIB): $(CSRC)/rt_host.o $(CSRC)/rt_image.o $(HIPOBJS)
 	$(HIPCC) --offload-arch=$(ARCH) -shared -fPIC -pthread -o $@ $^ -lz -ldl
 
+# (the kernel source includes "rt_trace_asm.inc" from its own directory: the stress build compiles a copy of the source beside a block of its own)
+build/stress/rt_trace_asm.inc: tools/gen_trace_asm.py
+	mkdir -p build/stress
+	RT_GEN_BATCH_MIN=1 RT_GEN_BATCH_WORK=0 python3 tools/gen_trace_asm.py $@ > /dev/null
+build/stress/rt_kernel_wave.hip: $(CSRC)/rt_kernel_wave.hip
+	mkdir -p build/stress
+	cp $< $@
+build/stress/rt_kernel_wave.o: build/stress/rt_kernel_wave.hip build/stress/rt_trace_asm.inc $(CSRC)/rt_kernels.h $(CSRC)/rt_internal.h $(CSRC)/rt_math.h include/rt_amd.h
+	$(HIPCC) $(HIPFLAGS) -I$(CSRC) -c $< -o $@
+$(STRESS): $(CSRC)/rt_host.o $(CSRC)/rt_image.o $(filter-out $(CSRC)/rt_kernel_wave.o,$(HIPOBJS)) build/stress/rt_kernel_wave.o
+	$(HIPCC) --offload-arch=$(ARCH) -shared -fPIC -pthread -o $@ $^ -lz -ldl
+
 $(RUN): $(CSRC)/run_main.cpp $(LIB) include/rt_amd.h
 	$(CXX) $(HOSTFLAGS) $< -o $@ -Lraytracer_amd -lrt_amd -Wl,-rpath,'$$ORIGIN'
 
@@ -34,7 +50,8 @@ oracle:
 	$(MAKE) -C oracle
 
 clean:
-	rm -f $(CSRC)/*.o $(LIB) $(RUN)
+	rm -f $(CSRC)/*.o $(LIB) $(RUN) $(STRESS)
+	rm -rf build/stress
 	$(MAKE) -C oracle clean
 
 .PHONY: all oracle clean
