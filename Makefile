@@ -16,7 +16,7 @@ RUN := raytracer_amd/run
 # too (tests/test_stress_variant.py) so that every scene walks through it.
 STRESS := raytracer_amd/librt_amd_stress.so
 
-all: $(LIB) $(RUN) $(STRESS) oracle
+all: $(LIB) $(RUN) $(STRESS) raytracer_amd/finish_check oracle
 
 $(CSRC)/rt_host.o: $(CSRC)/rt_host.cpp $(CSRC)/rt_internal.h include/rt_amd.h
 	$(CXX) $(HOSTFLAGS) -c $< -o $@
@@ -43,6 +43,11 @@ build/stress/rt_kernel_wave.o: build/stress/rt_kernel_wave.hip build/stress/rt_t
 $(STRESS): $(CSRC)/rt_host.o $(CSRC)/rt_image.o $(filter-out $(CSRC)/rt_kernel_wave.o,$(HIPOBJS)) build/stress/rt_kernel_wave.o
 	$(HIPCC) --offload-arch=$(ARCH) -shared -fPIC -pthread -o $@ $^ -lz -ldl
 
+# GPU check of the assembly block's decision routine for triangle candidates against the compiled form (tests/test_stress_variant.py runs it)
+raytracer_amd/finish_check: tools/gen_finish_check.py tools/gen_trace_asm.py
+	python3 tools/gen_finish_check.py > /dev/null
+	$(HIPCC) -O3 -ffp-contract=off --offload-arch=$(ARCH) build/finish_check.hip -o $@
+
 $(RUN): $(CSRC)/run_main.cpp $(LIB) include/rt_amd.h
 	$(CXX) $(HOSTFLAGS) $< -o $@ -Lraytracer_amd -lrt_amd -Wl,-rpath,'$$ORIGIN'
 
@@ -50,7 +55,7 @@ oracle:
 	$(MAKE) -C oracle
 
 clean:
-	rm -f $(CSRC)/*.o $(LIB) $(RUN) $(STRESS)
+	rm -f $(CSRC)/*.o $(LIB) $(RUN) $(STRESS) raytracer_amd/finish_check
 	rm -rf build/stress
 	$(MAKE) -C oracle clean
 

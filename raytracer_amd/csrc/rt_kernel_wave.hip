@@ -136,7 +136,7 @@ __device__ __forceinline__ bool wave_bundle(uint64_t cls, const RtVec3& e, const
 #ifdef RT_WAVE_TIMES_CLK
 __device__ float* rt_dbg_ts();   // the `t` output of the launch (defined behind the kernel's argument block)
 #endif
-template <bool CULL>
+template <bool CULL, bool BARY>
 __device__ __forceinline__ uint64_t walk_asm(const float4* nodes, uint32_t variant, uint32_t zpat, const float4* tri_leaf, uint32_t top_first, uint32_t rem,
                                              uint64_t live, const RtVec3& e, const RtVec3& d, const RtVec3& inv, const RtVec3& fc, float neg_eb,
                                              float stop_t, Hit& hit, WaveStack& st, float* bary_lds, uint32_t cull, const RtBundle& bundle) {
@@ -147,15 +147,14 @@ __device__ __forceinline__ uint64_t walk_asm(const float4* nodes, uint32_t varia
                  b8 = uni(__float_as_uint(bundle.k1)), b9 = uni(__float_as_uint(bundle.bw));                   // third column of the triangle solve (triangle.cu:118-120)
   const v2f e_xy = {e.x, e.y}, c_zx = {c2.z, c2.x}, c_yz = {c2.y, c2.z}, c_yx = {c2.y, c2.x};
   uint64_t a_blk = (uint64_t)(uintptr_t)(nodes + 2 * (size_t)top_first);
-  uint32_t a_rem = rem | 0x100u, a_first = top_first, a_idx = 0u, a_rfirst = 0u, a_rmeta = 0u, a_tcur = 0u, a_tend = 0u, a_res = 0u, a_prim = 0u, a_sp = 0u;
-  uint64_t a_tmask = live, a_mine = live, a_live = live, a_acc = 0ull, a_und = 0ull, a_pass = 0ull, a_chg = 0ull;
+  uint32_t a_rem = rem | 0x100u, a_first = top_first, a_idx = 0u, a_rfirst = 0u, a_rmeta = 0u, a_res = 0u, a_sp = 0u;
+  uint64_t a_tmask = live, a_mine = live, a_live = live, a_acc = 0ull, a_und = 0ull;
   const uint64_t a_tri = (uint64_t)(uintptr_t)tri_leaf;
-  // (the loop with four record sets parks s[68:83] while its leaf is open and may leave for the quotients with records in
-  //  them: the node array's address is an operand that comes back changed, like the rest of that range)
+  // (the loop with four record sets takes s[68:83] over while its leaf is open and puts the node array's address back
+  //  afterwards: an operand that is written, like the rest of that range)
   uint64_t a_nodes = (uint64_t)(uintptr_t)nodes;
   uint32_t a_work = 0u;   // triangles met in large leaves so far: the block treats a walk with many of them differently (see the register map at the call)
   const float cmax = rt_max3(fabsf(fc.x), fabsf(fc.y), fabsf(fc.z));
-  float a_det = 0.f, a_nb = 0.f, a_ng = 0.f, a_nt = 0.f;
 #ifdef RT_WAVE_TIMES_CLK
   uint32_t dbg_n1 = 0u, dbg_n2 = 0u; unsigned long long dbg_out = 0ull;
 #endif
@@ -170,41 +169,41 @@ __device__ __forceinline__ uint64_t walk_asm(const float4* nodes, uint32_t varia
 #endif
   // (one copy of the block per kind of node test inside the one statement: sign-uniform rays (0), or the rays' common
   //  zero pattern (1..6), chosen by s18)
+  // Operand lists of the four forms of the block (with / without the bundle test; barycentrics to registers / to LDS).
+#define RT_WALK_OUTPUTS \
+            "+{s[68:69]}"(a_blk), "+{s70}"(a_rem), "+{s71}"(a_first), "+{s[72:73]}"(a_tmask), "+{s[74:75]}"(a_mine), "+{s[76:77]}"(a_live), \
+            "+{s78}"(a_idx), "+{s79}"(a_rfirst), "+{s80}"(a_rmeta), "+{s[34:35]}"(a_acc), "+{s[96:97]}"(a_und), \
+            "+{s30}"(a_res), "+{m0}"(a_sp) RT_COUNT_OPERAND, \
+            "+{v60}"(st.first), "+{v61}"(st.cur), "+{v62}"(st.mask_lo), "+{v63}"(st.mask_hi), \
+            "+{s[82:83]}"(a_nodes), "+{s23}"(a_work), "+{v58}"(hit.t), [prim] "+v"(hit.prim)
+#define RT_WALK_INPUTS \
+            "{s[32:33]}"(a_tri), "{s18}"(zpat), "{v[40:41]}"(e_xy), "{v42}"(e.z), "{v[44:45]}"(c_zx), "{v[46:47]}"(c_yz), \
+            "{v[48:49]}"(c_yx), "{v50}"(inv.x), "{v51}"(inv.y), "{v52}"(inv.z), "{v53}"(fc.x), "{v54}"(fc.y), "{v55}"(fc.z), "{v56}"(cmax), \
+            "{v57}"(neg_eb), "{v59}"(stop_t)
+#define RT_WALK_BUNDLE \
+            , "{s19}"(cull), [b0] "s"(b0), [b1] "s"(b1), [b2] "s"(b2), [b3] "s"(b3), [b4] "s"(b4), [b5] "s"(b5), [b6] "s"(b6), [b7] "s"(b7), [b8] "s"(b8), [b9] "s"(b9)
+#define RT_WALK_CLOBBERS \
+            "s20", "s21", "s22", "s24", "s25", "s26", "s27", "s28", "s29", "s31", "s92", "s93", "s94", "s95", "s98", "s99", "s81", \
+            "s36", "s37", "s38", "s39", "s40", "s41", "s42", "s43", "s44", "s45", "s46", "s47", "s48", "s49", "s50", "s51", "s52", "s53", "s54", "s55", \
+            "s56", "s57", "s58", "s59", "s60", "s61", "s62", "s63", "s64", "s65", "s66", "s67", "s84", "s85", "s86", "s87", "s88", "s89", "s90", "s91", \
+            "v32", "v33", "v34", "v35", "v36", "v37", "v38", "v39", "v64", "v65", "v66", "v67", "v68", "v69", "v70", "v71", "v72", "v73", "v74", \
+            "v75", "v76", "v77", "v78", "v79", "vcc", "scc", "memory"
+  // (barycentrics in LDS: the wave's two columns, lane by lane; the block adds the lane's offset itself)
+  const uint32_t bary_addr = BARY ? uni((uint32_t)(uintptr_t)(__attribute__((address_space(3))) float*)bary_lds) : 0u;
   for (;;) {
-    if constexpr (CULL) {
-      asm volatile(RT_TRACE_ASM_CULL
-          : "+{s[68:69]}"(a_blk), "+{s70}"(a_rem), "+{s71}"(a_first), "+{s[72:73]}"(a_tmask), "+{s[74:75]}"(a_mine), "+{s[76:77]}"(a_live),
-            "+{s78}"(a_idx), "+{s79}"(a_rfirst), "+{s80}"(a_rmeta), "+{s[34:35]}"(a_acc), "+{s[96:97]}"(a_und), "+{s[28:29]}"(a_pass),
-            "+{s20}"(a_tcur), "+{s22}"(a_tend), "+{s[24:25]}"(a_chg), "+{s30}"(a_res), "+{s31}"(a_prim), "+{m0}"(a_sp) RT_COUNT_OPERAND,
-            "+{v60}"(st.first), "+{v61}"(st.cur), "+{v62}"(st.mask_lo), "+{v63}"(st.mask_hi),
-            "={v32}"(a_det), "={v33}"(a_nb), "={v35}"(a_ng), "={v36}"(a_nt), "+{s[82:83]}"(a_nodes), "+{s23}"(a_work)
-          : "{s[32:33]}"(a_tri), "{s18}"(zpat), "{s19}"(cull), "{v[40:41]}"(e_xy), "{v42}"(e.z), "{v[44:45]}"(c_zx), "{v[46:47]}"(c_yz),
-            "{v[48:49]}"(c_yx), "{v50}"(inv.x), "{v51}"(inv.y), "{v52}"(inv.z), "{v53}"(fc.x), "{v54}"(fc.y), "{v55}"(fc.z), "{v56}"(cmax),
-            "{v57}"(neg_eb), "{v58}"(hit.t), "{v59}"(stop_t),
-            [b0] "s"(b0), [b1] "s"(b1), [b2] "s"(b2), [b3] "s"(b3), [b4] "s"(b4), [b5] "s"(b5), [b6] "s"(b6), [b7] "s"(b7), [b8] "s"(b8), [b9] "s"(b9)
-          : "s92", "s93", "s94", "s95", "s36", "s37", "s38", "s39", "s40", "s41", "s42", "s43", "s44", "s45", "s46", "s47", "s48", "s49", "s50", "s51", "s52", "s53", "s54", "s55",
-            "s56", "s57", "s58", "s59", "s60", "s61", "s62", "s63", "s64", "s65", "s66", "s67", "s81", "s84", "s85", "s86", "s87", "s88", "s89", "s90",
-            "s91", "s98", "s99", "s26", "s27", "s21", "v34", "v37", "v38", "v39", "v64", "v65", "v66", "v67", "v68", "v69", "v70", "v71", "v72", "v73", "v74",
-            "v75", "v76", "v77", "v78", "v79", "vcc", "scc");
+    if constexpr (CULL && BARY) {
+      asm volatile(RT_TRACE_ASM_CULL_LDS : RT_WALK_OUTPUTS : RT_WALK_INPUTS RT_WALK_BUNDLE, [bary] "s"(bary_addr), [boff] "n"(RT_WBLOCK * 4) : RT_WALK_CLOBBERS);
+    } else if constexpr (CULL) {
+      asm volatile(RT_TRACE_ASM_CULL_REG : RT_WALK_OUTPUTS, [bet] "+v"(hit.bet), [gam] "+v"(hit.gam) : RT_WALK_INPUTS RT_WALK_BUNDLE : RT_WALK_CLOBBERS);
+    } else if constexpr (BARY) {
+      asm volatile(RT_TRACE_ASM_PLAIN_LDS : RT_WALK_OUTPUTS : RT_WALK_INPUTS, [bary] "s"(bary_addr), [boff] "n"(RT_WBLOCK * 4) : RT_WALK_CLOBBERS);
     } else {
-      asm volatile(RT_TRACE_ASM_PLAIN
-          : "+{s[68:69]}"(a_blk), "+{s70}"(a_rem), "+{s71}"(a_first), "+{s[72:73]}"(a_tmask), "+{s[74:75]}"(a_mine), "+{s[76:77]}"(a_live),
-            "+{s78}"(a_idx), "+{s79}"(a_rfirst), "+{s80}"(a_rmeta), "+{s[34:35]}"(a_acc), "+{s[96:97]}"(a_und), "+{s[28:29]}"(a_pass),
-            "+{s20}"(a_tcur), "+{s22}"(a_tend), "+{s[24:25]}"(a_chg), "+{s30}"(a_res), "+{s31}"(a_prim), "+{m0}"(a_sp) RT_COUNT_OPERAND,
-            "+{v60}"(st.first), "+{v61}"(st.cur), "+{v62}"(st.mask_lo), "+{v63}"(st.mask_hi),
-            "={v32}"(a_det), "={v33}"(a_nb), "={v35}"(a_ng), "={v36}"(a_nt), "+{s[82:83]}"(a_nodes), "+{s23}"(a_work)
-          : "{s[32:33]}"(a_tri), "{s18}"(zpat), "{v[40:41]}"(e_xy), "{v42}"(e.z), "{v[44:45]}"(c_zx), "{v[46:47]}"(c_yz),
-            "{v[48:49]}"(c_yx), "{v50}"(inv.x), "{v51}"(inv.y), "{v52}"(inv.z), "{v53}"(fc.x), "{v54}"(fc.y), "{v55}"(fc.z), "{v56}"(cmax),
-            "{v57}"(neg_eb), "{v58}"(hit.t), "{v59}"(stop_t)
-          : "s92", "s93", "s94", "s95", "s36", "s37", "s38", "s39", "s40", "s41", "s42", "s43", "s44", "s45", "s46", "s47", "s48", "s49", "s50", "s51", "s52", "s53", "s54", "s55",
-            "s56", "s57", "s58", "s59", "s60", "s61", "s62", "s63", "s64", "s65", "s66", "s67", "s81", "s84", "s85", "s86", "s87", "s88", "s89", "s90",
-            "s91", "s98", "s99", "s26", "s27", "s21", "v34", "v37", "v38", "v39", "v64", "v65", "v66", "v67", "v68", "v69", "v70", "v71", "v72", "v73", "v74",
-            "v75", "v76", "v77", "v78", "v79", "vcc", "scc");
+      asm volatile(RT_TRACE_ASM_PLAIN_REG : RT_WALK_OUTPUTS, [bet] "+v"(hit.bet), [gam] "+v"(hit.gam) : RT_WALK_INPUTS : RT_WALK_CLOBBERS);
     }
     if (a_res == 0u) break;
 #ifdef RT_WAVE_TIMES_CLK
     const unsigned long long dbg_t0 = __builtin_amdgcn_s_memtime();
-    if (a_res == 1u) dbg_n1++; else dbg_n2++;
+    dbg_n1++;
 #endif
     if (a_res == 1u) {
       // the exact test for the lanes in a_und: the planes of the child just tested are read again
@@ -228,17 +227,6 @@ __device__ __forceinline__ uint64_t walk_asm(const float4* nodes, uint32_t varia
         pos_m = (pos_m & ~tie_m) | (__builtin_amdgcn_ballot_w64(ex) & tie_m);
       }
       a_acc |= pos_m & a_und;
-    } else if (in_mask(a_pass)) {   // the reference's quotients decide (triangle.cu:131-137)
-      RtTriNum n;
-      n.det = a_det; n.nb = a_nb; n.ng = a_ng; n.nt = a_nt;
-      float t = 0.f, bet = 0.f, gam = 0.f;
-      const bool ok = rt_triangle_finish(n, hit.t, t, bet, gam);
-      asm volatile("" : "+v"(t), "+v"(bet), "+v"(gam));   // (three values known here, used below: not a merge of two paths, which would go through scratch memory)
-      if (ok) {
-        hit.t = t; hit.prim = (int32_t)a_prim;
-        if (bary_lds) { float* const mine = bary_lds + fresh_lane_id(); mine[0] = bet; mine[RT_WBLOCK] = gam; }
-        else { hit.bet = bet; hit.gam = gam; }
-      }
     }
 #ifdef RT_WAVE_TIMES_CLK
     dbg_out += __builtin_amdgcn_s_memtime() - dbg_t0;
@@ -255,6 +243,11 @@ __device__ __forceinline__ uint64_t walk_asm(const float4* nodes, uint32_t varia
       uint32_t* const stg = (uint32_t*)ts + (1u << 22) + (1u << 20) + 8u * blockIdx.x;
       atomicAdd(stg + 0, a_iter & 0xffffu); atomicAdd(stg + 1, a_stage & 0xffffu); atomicAdd(stg + 2, a_stage >> 16); atomicAdd(stg + 3, a_iter >> 16);
       atomicAdd(stg + 4, a_enter & 0xffffu); atomicAdd(stg + 5, a_enter >> 16); atomicAdd(stg + 6, a_tail & 0xffffu); atomicAdd(stg + 7, a_tail >> 16);
+#if RT_STAGE_COUNT == 2
+      // (block generated with RT_GEN_COUNT=leaf: the four registers count something else; totals over the launches of the frame)
+      uint32_t* const lf = (uint32_t*)ts + (1u << 22) + (1u << 21) + (1u << 20);
+      atomicAdd(lf + 0, a_iter); atomicAdd(lf + 1, a_enter); atomicAdd(lf + 2, a_tail); atomicAdd(lf + 3, a_stage); atomicAdd(lf + 4, 1u);
+#endif
 #endif
     }
   }
@@ -405,7 +398,7 @@ __device__ __forceinline__ void trace_wave(const float4* __restrict__ nodes, int
     if ((presorted || zpat != 0u) && FUSED && (rem & 0xffu) != 0u) {
       RtBundle bundle = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
       const uint32_t cull = (CULLABLE && cull_offset != 0u && wave_bundle(live, e, d, stop_t, bundle, cull_r0_max, cull_ksp_max)) ? cull_offset : 0u;
-      live = walk_asm<CULLABLE>(nodes, variant, zpat, tri_leaf, top_first, rem, live, e, d, inv, fc, neg_eb, stop_t, hit, st, nullptr, cull, bundle);
+      live = walk_asm<CULLABLE, false>(nodes, variant, zpat, tri_leaf, top_first, rem, live, e, d, inv, fc, neg_eb, stop_t, hit, st, nullptr, cull, bundle);
       if (!live) return;
     } else {
 #endif
@@ -900,7 +893,7 @@ __device__ __forceinline__ uint64_t trace_class(const float4* __restrict__ nodes
       }
       RtBundle bundle = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
       const uint32_t cull = (CULLABLE && cull_offset != 0u && wave_bundle(cls, e, d, stop_t, bundle, cull_r0_max, cull_ksp_max)) ? cull_offset : 0u;
-      after = walk_asm<CULLABLE>(vnodes, variant, zpat, tri_leaf, top_first, rem, cls, e, d, inv, fu.c, neg_eb, stop_t, hit, st, bary_lds, cull, bundle);
+      after = walk_asm<CULLABLE, true>(vnodes, variant, zpat, tri_leaf, top_first, rem, cls, e, d, inv, fu.c, neg_eb, stop_t, hit, st, bary_lds, cull, bundle);
     }
   }
   if (n_spheres > 0 && after) {

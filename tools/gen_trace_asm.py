@@ -66,6 +66,12 @@ WORK = "s23"                      # triangles the walk has met in leaves with BI
                                   # loop with four sets the register is J[3], and WORK0 again behind it)
 
 
+def counting():
+    """RT_GEN_COUNT=1: the block counts its steps in s14 .. s17 (measurement builds, -DRT_STAGE_COUNT); RT_GEN_COUNT=leaf: it counts
+    instead how many triangles leaves hold that few rays of the wave enter (-DRT_STAGE_COUNT=2)."""
+    return os.environ.get("RT_GEN_COUNT") not in (None, "", "0", "leaf")
+
+
 def s(n):
     return "s%d" % n
 
@@ -80,7 +86,7 @@ def scan_sorted():
     L = []
     # (scalar loads return out of order: before a record is requested into registers that an earlier request - the sibling
     #  behind the one that was accepted, the triangle behind a leaf's last - may still be on its way into, that one is awaited)
-    L += ["LT_enter_%=:"] + (["s_add_u32 %s, %s, 1" % ("s15", "s15")] if os.environ.get("RT_GEN_COUNT") else []) + [
+    L += ["LT_enter_%=:"] + (["s_add_u32 %s, %s, 1" % ("s15", "s15")] if counting() else []) + [
           "s_ff1_i32_b32 %s, %s" % (IDX, REM),
           "s_lshl_b32 %s, %s, 5" % (OFF, IDX),
           "s_waitcnt lgkmcnt(0)",
@@ -88,7 +94,7 @@ def scan_sorted():
           "LT_scan_%=:",
           "s_bitset0_b32 %s, %s" % (REM, IDX),
           "s_waitcnt lgkmcnt(0)"]
-    if os.environ.get("RT_GEN_COUNT"):
+    if counting():
         L.append("s_add_u32 %s, %s, 0x10000" % ("s14", "s14"))
     for i, (inv, fc) in enumerate(((IX, FCX), (IX, FCX), (IY, FCY), (IY, FCY), (IZ, FCZ), (IZ, FCZ))):
         L.append("v_fma_f32 %s, %s, %s, -%s" % (t[i], s(NX + i), inv, fc))
@@ -187,7 +193,7 @@ def scan_zero(pattern):
     mnmx = [("v70", "v71"), ("v72", "v73")]
     SQ = T64
     INALL = "s[98:99]"   # (NR is consumed before the tail needs this)
-    L = ["LT_enter_%=:"] + (["s_add_u32 %s, %s, 1" % ("s15", "s15")] if os.environ.get("RT_GEN_COUNT") else []) + [
+    L = ["LT_enter_%=:"] + (["s_add_u32 %s, %s, 1" % ("s15", "s15")] if counting() else []) + [
          "s_ff1_i32_b32 %s, %s" % (IDX, REM),
          "s_lshl_b32 %s, %s, 5" % (OFF, IDX),
          "s_waitcnt lgkmcnt(0)",
@@ -195,7 +201,7 @@ def scan_zero(pattern):
          "LT_scan_%=:",
          "s_bitset0_b32 %s, %s" % (REM, IDX),
          "s_waitcnt lgkmcnt(0)"]
-    if os.environ.get("RT_GEN_COUNT"):
+    if counting():
         L.append("s_add_u32 %s, %s, 0x10000" % ("s14", "s14"))
     for i in range(6):
         L.append("v_sub_f32 %s, %s, %s" % (d[i], s(NX + i), ev[i // 2]))
@@ -385,28 +391,85 @@ def triangle(q, other, tag, cur, nxt, masked):
          "s_and_b64 %s, %s, vcc" % (T64, T64),
          "s_and_b64 %s, %s, %s" % (PASS, PASS, T64),
          "s_cbranch_scc0 LT_end%s_%%=" % tag,
-         # candidates: the quotients are formed outside; the walk goes on behind this record
-         "s_mov_b32 %s, %s" % (RPRIM, s(q + 3)),
-         "s_mov_b32 %s, %s" % (TCUR, nxt),                                                       # where the leaf goes on afterwards
-         "@SAVE",
-         "@RES",
-         "s_branch LT_out_%=",
+         # candidates: the reference's quotients decide (LT_finish); the walk goes on behind this record
+         "s_or_b64 %s, %s, %s" % (CHG, CHG, PASS)] + call_finish(q) + [
          "LT_end%s_%%=:" % tag]
     out = []
     for line in L:
         if line == "@NEXT":
             out += (["s_ff1_i32_b64 %s, %s" % (JT, SURV), "s_bitset0_b64 %s, %s" % (SURV, JT), "s_add_u32 %s, %s, %s" % (JT, JT, RFIRST),
                      "s_lshl_b32 %s, %s, 6" % (nxt, JT)] if masked else ["s_add_u32 %s, %s, 0x40" % (nxt, cur)])
-        elif line == "@RES":
-            out.append("s_mov_b32 %s, %d" % (RES, 2 if masked else 3))     # (which of the two leaf loops to come back to)
         elif line.startswith("@COUNT"):
-            if os.environ.get("RT_GEN_COUNT"):
+            if counting():
                 out.append(count_instr(line))
-        elif line == "@SAVE":
-            out += ["v_writelane_b32 %s, s98, 62" % ST_FIRST, "v_writelane_b32 %s, s99, 63" % ST_FIRST] if masked else []
         else:
             out.append(line)
     return out
+
+
+def call_finish(q):
+    """Candidates in PASS (SCC is 1: the mask operation before found some): the lanes of the wave become the candidates, the
+    routine below decides them with the reference's quotients and comes back to the branch here with SCC = 0."""
+    return ["s_mov_b64 %s, exec" % T64,
+            "s_mov_b64 exec, %s" % PASS,
+            "s_mov_b32 s28, vcc_lo",                                       # (the loop with four sets keeps the leaf's first record index there)
+            "s_mov_b32 s29, %s" % s(q + 3),                                # the triangle's id
+            "s_getpc_b64 %s" % TMPP,
+            "s_cbranch_scc1 LT_finish_%="]
+
+
+def divide(out, num, den):
+    """out = num / den, correctly rounded (the sequence the compiler emits for a float division: scale, reciprocal, two
+    refinements of the reciprocal's error and of the quotient, fix-up).  v34 v37 v38 v39 are its scratch."""
+    A, B, C, D = "v37", "v38", "v39", "v34"
+    return ["v_div_scale_f32 %s, vcc, %s, %s, %s" % (A, den, den, num),
+            "v_rcp_f32 %s, %s" % (B, A),
+            "s_nop 0",                                                      # (gfx950: one wait state between a transcendental and an instruction of another kind that reads its result; the assembler adds none in inline assembly)
+            "v_fma_f32 %s, -%s, %s, 1.0" % (C, A, B),
+            "v_fma_f32 %s, %s, %s, %s" % (B, C, B, B),
+            "v_div_scale_f32 %s, vcc, %s, %s, %s" % (D, num, den, num),
+            "v_mul_f32 %s, %s, %s" % (out, D, B),
+            "v_fma_f32 %s, -%s, %s, %s" % (C, A, out, D),
+            "v_fma_f32 %s, %s, %s, %s" % (out, C, B, out),
+            "v_fma_f32 %s, -%s, %s, %s" % (C, A, out, D),
+            "v_div_fmas_f32 %s, %s, %s, %s" % (out, C, B, out),             # (four instructions behind the scale that wrote vcc: the wait it needs)
+            "v_div_fixup_f32 %s, %s, %s, %s" % (out, out, den, num)]
+
+
+def finish(bary):
+    """The final decision for the candidates of a triangle (triangle.cu:131-137, rt_triangle_finish in rt_math.h): beta, gamma and
+    t as quotients by the determinant, 0 < t < closest hit so far, 0 <= beta, gamma <= 1, 0 <= 1 - beta - gamma.  The lanes that
+    pass take t, the triangle's id and the barycentrics (registers of the caller, or the wave's two columns in LDS)."""
+    det, nb, ng, nt = "v32", "v33", "v35", "v36"
+    x0, x1, x2, alp = "v64", "v65", "v66", "v67"
+    L = ["LT_finish_%=:"]
+    L += divide(x0, nb, det) + divide(x1, ng, det) + divide(x2, nt, det)
+    L += ["v_sub_f32 %s, 1.0, %s" % (alp, x0),
+          "v_sub_f32 %s, %s, %s" % (alp, alp, x1),
+          "v_cmpx_lt_f32 vcc, 0, %s" % x2,
+          "v_cmpx_gt_f32 vcc, %s, %s" % (T, x2),
+          "v_cmpx_le_f32 vcc, 0, %s" % x0,
+          "v_cmpx_ge_f32 vcc, 1.0, %s" % x0,
+          "v_cmpx_le_f32 vcc, 0, %s" % x1,
+          "v_cmpx_ge_f32 vcc, 1.0, %s" % x1,
+          "v_cmpx_le_f32 vcc, 0, %s" % alp,
+          "v_mov_b32 %s, %s" % (T, x2),
+          "v_mov_b32 %[prim], s29"]
+    if bary:
+        L += ["v_mbcnt_lo_u32_b32 v68, -1, 0",
+              "v_mbcnt_hi_u32_b32 v68, -1, v68",
+              "v_lshlrev_b32 v68, 2, v68",
+              "v_add_u32 v68, %[bary], v68",
+              "ds_write_b32 v68, %s" % x0,
+              "ds_write_b32 v68, %s offset:%%[boff]" % x1]
+    else:
+        L += ["v_mov_b32 %%[bet], %s" % x0,
+              "v_mov_b32 %%[gam], %s" % x1]
+    L += ["s_mov_b32 vcc_lo, s28",
+          "s_mov_b64 exec, %s" % T64,
+          "s_cmp_lg_u32 0, 0",                                             # SCC = 0: the branch that called falls through
+          "s_setpc_b64 %s" % TMPP]
+    return L
 
 
 def cull():
@@ -467,6 +530,13 @@ def leaf(with_cull):
     L = ["LT_leaf_%=:", "@COUNT_LEAF",
          "s_and_b32 %s, %s, 0xff" % (TEND, RMETA),
          "s_cbranch_scc0 LT_next_%="]
+    if os.environ.get("RT_GEN_COUNT") == "leaf":
+        # (-DRT_STAGE_COUNT=2) how many triangles leaves hold that few rays of the wave enter: s14 all, s15 / s16 entered by at most 2 / 4 rays, s17 triangles x rays
+        L += ["s_bcnt1_i32_b64 s30, %s" % ACC,
+              "s_add_u32 s14, s14, %s" % TEND,
+              "s_cmp_le_u32 s30, 2", "s_cselect_b32 s31, %s, 0" % TEND, "s_add_u32 s15, s15, s31",
+              "s_cmp_le_u32 s30, 4", "s_cselect_b32 s31, %s, 0" % TEND, "s_add_u32 s16, s16, s31",
+              "s_mul_i32 s31, s30, %s" % TEND, "s_add_u32 s17, s17, s31"]
     if with_cull:
         L += leaf_masked()
     L += leaf_all()
@@ -554,9 +624,8 @@ def batch_issue(slot, tmp):
             "s_load_dwordx16 s[%d:%d], s[%s:%s], %s" % (q, q + 15, TRI[0][1:], TRI[1][1:], tmp)]
 
 
-def batch_test(slot, pending):
-    """The three numerator stages on record set `slot`.  With candidates the walk leaves for the quotients: the records that
-    were requested and not tested yet (`pending`) go back into SURVB, which waits in lanes 62 / 63 of ST_FIRST with RF in lane 61."""
+def batch_test(slot):
+    """The three numerator stages on record set `slot`; candidates are decided by LT_finish."""
     q = RSET[slot]
     bxy, bz = "v[68:69]", "v74"
     bx, by = "v68", "v69"
@@ -619,14 +688,9 @@ def batch_test(slot, pending):
          "s_and_b64 %s, %s, %s" % (T64, T64, TMPP),
          "s_and_b64 %s, %s, %s" % (PASS, PASS, T64),
          "s_cbranch_scc0 LT_e%s_%%=" % tag,
-         "s_mov_b32 %s, %s" % (RPRIM, s(q + 3))]
-    L += ["s_bitset1_b64 %s, %s" % (SURVB, J[j]) for j in pending]
-    L += ["v_writelane_b32 %s, %s, 62" % (ST_FIRST, SURVB_LO),
-          "v_writelane_b32 %s, %s, 63" % (ST_FIRST, SURVB_HI),
-          "v_writelane_b32 %s, %s, 61" % (ST_FIRST, RF),
-          "s_mov_b32 %s, 4" % RES,
-          "s_branch LT_out_%=",
-          "LT_e%s_%%=:" % tag]
+         "s_bitset1_b32 %s, 30" % RF]
+    L += call_finish(q)
+    L += ["LT_e%s_%%=:" % tag]
     return L
 
 
@@ -655,13 +719,13 @@ def leaf_big(with_cull):
           "s_cbranch_scc0 LT_noq_%="]
     L += batch_issue(2, TMP0) + batch_issue(3, TMP1)
     L += ["LT_p0_%=:"]
-    L += batch_test(0, (1, 2, 3)) + batch_test(1, (2, 3))
+    L += batch_test(0) + batch_test(1)
     L += ["s_waitcnt lgkmcnt(0)",
           "s_lshl_b64 %s, %s, 1" % (TMPP, SURVB),
           "s_cbranch_scc0 LT_nop_%="]
     L += batch_issue(0, TMP0) + batch_issue(1, TMP1)
     L += ["LT_q0_%=:"]
-    L += batch_test(2, (3, 0, 1)) + batch_test(3, (0, 1))
+    L += batch_test(2) + batch_test(3)
     L += ["s_branch LT_lp_%=",
           "LT_noq_%=:", "s_mov_b32 %s, 63" % J[2], "s_mov_b32 %s, 63" % J[3], "s_branch LT_p0_%=",
           "LT_nop_%=:", "s_mov_b32 %s, 63" % J[0], "s_mov_b32 %s, 63" % J[1], "s_branch LT_q0_%=",
@@ -674,61 +738,26 @@ def leaf_big(with_cull):
           "s_load_dwordx8 s[84:91], %s, %s" % (BLK, OFF),               # the sibling behind the leaf, whose record gave way
           "s_bitcmp1_b32 %s, 30" % RF,
           "s_cbranch_scc0 LT_next_%=",
-          "s_branch LT_leaf_changed_%=",
-          "LT_resume_big_%=:",
-          "v_readlane_b32 %s, %s, 62" % (SURVB_LO, ST_FIRST),
-          "v_readlane_b32 %s, %s, 63" % (SURVB_HI, ST_FIRST),
-          "v_readlane_b32 %s, %s, 61" % (RF, ST_FIRST),
-          "s_nop 1",
-          "s_bitset1_b32 %s, 30" % RF,
-          "s_lshl_b64 %s, %s, 1" % (TMPP, SURVB),
-          "s_cbranch_scc0 LT_unpark_%=",
-          "s_branch LT_big_start_%="]
+          "s_branch LT_leaf_changed_%="]
     return L
 
 
-def block(pattern, with_cull):
-    # (a walk that starts is the most frequent way in; of the re-entries a wave with a long life makes most behind candidates
-    #  of the loop with four sets: a compare and a branch not taken cost a lone wave 24 cycles)
+def block(pattern, with_cull, bary):
+    # The block leaves for one thing only and is entered again afterwards: the exact node test of lanes that the
+    # classification could not decide (RES = 1).  RES = 0: the walk is over.
     L = ["s_waitcnt lgkmcnt(0)",
-         "s_cmp_eq_u32 %s, 0" % RES,
-         "s_cbranch_scc1 LT_enter_%="]
-    if BATCH:
-        L += ["s_cmp_eq_u32 %s, 4" % RES,
-              "s_cbranch_scc1 LT_resume_big_%="]
-    L += ["s_cmp_eq_u32 %s, 1" % RES,
-          "s_cbranch_scc1 LT_resume_exact_%="]
-    if with_cull:
-        L += ["s_cmp_eq_u32 %s, 2" % RES,
-              "s_cbranch_scc1 LT_resume_finish_%="]
-    L += ["s_branch LT_resume_finish_all_%="]
+         "s_cmp_eq_u32 %s, 1" % RES,
+         "s_cbranch_scc1 LT_resume_exact_%="]
     L += scan_sorted() if pattern == 0 else scan_zero(pattern)
     L += leaf(with_cull)
     if BATCH:
         L += leaf_big(with_cull)
-    L += [# ---- re-entries: the record of the next sibling is requested again (its registers were not kept outside)
+    L += finish(bary)
+    L += [# ---- re-entry: the record of the next sibling is requested again (its registers were not kept outside)
           "LT_resume_exact_%=:",
           "s_lshl_b32 %s, %s, 5" % (OFF, IDX),
           "s_load_dwordx8 s[84:91], %s, %s" % (BLK, OFF),
-          "s_branch LT_after_exact_%="]
-    if with_cull:
-        L += ["LT_resume_finish_%=:",
-              "s_lshl_b32 %s, %s, 5" % (OFF, IDX),
-              "s_load_dwordx8 s[84:91], %s, %s" % (BLK, OFF),
-              "s_or_b64 %s, %s, %s" % (CHG, CHG, PASS),
-              "v_readlane_b32 s98, %s, 62" % ST_FIRST,
-              "v_readlane_b32 s99, %s, 63" % ST_FIRST,
-              "s_nop 0",
-              "s_cmp_eq_u64 %s, 0" % SURV,
-              "s_cbranch_scc1 LT_leaf_done_%=",
-              "s_branch LT_leaf_load_%="]
-    L += ["LT_resume_finish_all_%=:",
-          "s_lshl_b32 %s, %s, 5" % (OFF, IDX),
-          "s_load_dwordx8 s[84:91], %s, %s" % (BLK, OFF),
-          "s_or_b64 %s, %s, %s" % (CHG, CHG, PASS),
-          "s_cmp_lt_u32 %s, %s" % (TCUR, TEND),
-          "s_cbranch_scc0 LT_leaf_done_%=",
-          "s_branch LT_leaf_load_all_%=",
+          "s_branch LT_after_exact_%=",
           "LT_exit_exact_%=:",
           "s_mov_b32 %s, 1" % RES,
           "s_branch LT_out_%=",
@@ -739,7 +768,7 @@ def block(pattern, with_cull):
     return L
 
 
-def statement(with_cull):
+def statement(with_cull, bary):
     # ONE assembly statement with the seven copies behind a dispatch on the pattern (s18): several statements in a
     # switch would have the compiler merge their scalar outputs through values it no longer knows to be wave-uniform
     L = ["s_cmp_eq_u32 s18, 0", "s_cbranch_scc1 LT0_begin_%="]       # (nearly every walk)
@@ -747,7 +776,7 @@ def statement(with_cull):
         L += ["s_cmp_eq_u32 s18, %d" % pattern, "s_cbranch_scc1 LT%d_begin_%%=" % pattern]
     L += ["s_branch LT6_begin_%="]
     for pattern in range(7):
-        B = ["LT%d_begin_%%=:" % pattern] + block(pattern, with_cull) + ["s_branch LT_end_all_%="]
+        B = ["LT%d_begin_%%=:" % pattern] + block(pattern, with_cull, bary) + ["s_branch LT_end_all_%="]
         L += [line.replace("LT_", "LT%d_" % pattern) if "LT_end_all" not in line else line for line in B]
         print("cull" if with_cull else "plain", "pattern", pattern, len(B), "lines")
     L += ["LT_end_all_%=:"]
@@ -767,22 +796,19 @@ def main():
         out = sys.argv[1]
     with open(out, "w") as f:
         f.write("// Generated by tools/gen_trace_asm.py - do not edit.  Register map and operands: rt_kernel_wave.hip (walk_asm, trace_wave).\n")
-        f.write("// RT_TRACE_ASM_CULL: the walk with the bundle test in front of a leaf's triangles (operands %[b0] .. %[b9], s19);\n")
-        f.write("// RT_TRACE_ASM_PLAIN: the walk that tests every triangle of every leaf it enters (kernels whose rays never form a bundle).\n")
-        f.write("// In both, one copy per kind of node test: rays that agree on their direction signs (s18 = 0), rays that share a zero pattern (s18 = 1 .. 6, bit k: component k is zero).\n")
-        for name, with_cull in (("RT_TRACE_ASM_CULL", True), ("RT_TRACE_ASM_PLAIN", False)):
+        f.write("// RT_TRACE_ASM_CULL_*: the walk with the bundle test in front of a leaf's triangles (operands %[b0] .. %[b9], s19);\n")
+        f.write("// RT_TRACE_ASM_PLAIN_*: the walk that tests every triangle of every leaf it enters (kernels whose rays never form a bundle).\n")
+        f.write("// *_REG: the barycentrics of an accepted triangle go to the operands %[bet] / %[gam]; *_LDS: to the wave's two columns in LDS (%[bary], %[boff]).\n")
+        f.write("// In all, one copy per kind of node test: rays that agree on their direction signs (s18 = 0), rays that share a zero pattern (s18 = 1 .. 6, bit k: component k is zero).\n")
+        for name, with_cull, bary in (("RT_TRACE_ASM_CULL_REG", True, False), ("RT_TRACE_ASM_CULL_LDS", True, True),
+                                      ("RT_TRACE_ASM_PLAIN_REG", False, False), ("RT_TRACE_ASM_PLAIN_LDS", False, True)):
             f.write("#define %s \\\n" % name)
+            body = statement(with_cull, bary)
             if os.environ.get("RT_GEN_NOLOAD"):
-                body = statement(with_cull)
-                keep = []
-                for i, l in enumerate(body):
-                    prev = body[i - 1] if i else ""
-                    in_loop = ("s_load_dwordx16" in l and ("s_add_u32" in prev or "s_lshl_b32 s2" in prev))   # (only the triangle loops: without the siblings' records the scan would descend into the same child again and again)
-                    keep.append("s_nop 0" if in_loop else l)
-                statement_lines = keep
-            else:
-                statement_lines = statement(with_cull)
-            lines = [(count_instr(l) if l in COUNTERS else l) if os.environ.get("RT_GEN_COUNT") else l for l in statement_lines if l != "@PRIO" and (os.environ.get("RT_GEN_COUNT") or l not in COUNTERS)]
+                # (measurement: what a triangle iteration costs without the wait for its record.  Only the triangle loops: without
+                #  the siblings' records the scan would descend into the same child again and again)
+                body = ["s_nop 0" if ("s_load_dwordx16" in l and i and ("s_add_u32" in body[i - 1] or "s_lshl_b32 s2" in body[i - 1])) else l for i, l in enumerate(body)]
+            lines = [(count_instr(l) if l in COUNTERS else l) if counting() else l for l in body if l != "@PRIO" and (counting() or l not in COUNTERS)]
             f.write(" \\\n".join(emit(line) for line in lines))
             f.write("\n")
     print("wrote", os.path.normpath(out))
