@@ -373,9 +373,11 @@ __device__ __forceinline__ void trace_wave(const float4* __restrict__ nodes, int
     // pointer lives in M0), ascent, and the leaf loop with the three numerator stages of the triangle test on two sets
     // of record registers filled in turn.  What the compiler makes of the same walk spends most of its scalar
     // instructions moving records and lane masks between register sets; the scalar unit, which a compute unit's four
-    // SIMDs share, is what this kernel keeps busiest.  The block leaves for two things only and is entered again
-    // afterwards: the exact node test of lanes the classification could not decide (reason 1: about 1 % of the node
-    // tests) and the quotients of triangle candidates (reason 2: 2.5 % of the triangle tests).  Reason 0: the walk is over.
+    // SIMDs share, is what this kernel keeps busiest.  The block leaves for one thing only and is entered again
+    // afterwards: the exact node test of lanes the classification could not decide (reason 1: about 0.5 % of the node
+    // tests).  Reason 0: the walk is over.  The candidates of a triangle (2.5 % of the triangle tests) are decided by a
+    // routine of the block itself: the reference's three quotients as correctly rounded divisions, its seven compares,
+    // and the lanes that pass take t, the triangle's id and the barycentrics (operands, or the wave's columns in LDS).
     // Registers (fixed, named in the generator): s[36:67] two triangle records, s[68:69] address of the current
     // branch's children, s70 children left (bit 8 always set: "child 8" is the record behind the block, requested but
     // never tested), s71 index of child 0, s[72:73] lanes that entered the branch, s[74:75] those of them still
@@ -383,18 +385,18 @@ __device__ __forceinline__ void trace_wave(const float4* __restrict__ nodes, int
     // just tested, s81 byte offset, s[82:83] node array, s[32:33] triangle array, s[34:35] accepted lanes, s[96:97] undecided lanes,
     // s[28:29] triangle candidates, s20 / s21 byte offsets of the triangle record under test and the next one to be tested, s22 offset
     // behind the leaf's last record (in a leaf whose triangles were put in front of the wave's bundle first: scratch), s[24:25] lanes
-    // whose hit changed in the leaf, s30 reason / re-entry (2 / 3 / 4: which of the leaf loops), s31 id of the candidate triangle,
-    // s19 byte offset of the RtCullRec array (0: no bundle), s[98:99] within such a leaf the triangles still to be tested (outside
-    // the block they wait in lanes 62 / 63 of v60), ten scalar operands for the bundle; v[40:59] the ray
+    // whose hit changed in the leaf, s30 reason / re-entry, s[30:31] the address the decision routine comes back to,
+    // s19 byte offset of the RtCullRec array (0: no bundle), s[98:99] within such a leaf the triangles still to be tested,
+    // ten scalar operands for the bundle; v[40:59] the ray
     // (origin, negated direction in the pairs the first stage multiplies, inverse direction, e * inv, margin terms,
-    // closest hit so far, shadow-ray length), v[60:63] the wave's stack, v32 v33 v35 v36 determinant and numerators
-    // of a candidate, v34 v37:v39 v64:v79 scratch.
+    // closest hit so far - which the decision routine moves -, shadow-ray length), v[60:63] the wave's stack, v32 v33 v35 v36
+    // determinant and numerators of a candidate, v34 v37:v39 v64:v79 scratch.
     // A walk with a long life ahead - one that has met 64 triangles in leaves with six or more to test; s23 counts them -
-    // takes such leaves through a loop with FOUR record sets (re-entry 4): s[68:83] and s[84:99] hold records too, the
-    // traversal state that lives there waits in lanes 32 .. 44 of v61, s20 .. s23 are the leaf-relative indices of the
-    // records in the four sets, s[24:25] the triangles still to request, vcc_lo the leaf's first record (outside the
-    // block: lane 61 of v60).  Two records are tested while the next two are on their way: a scalar load
-    // takes such a wave about 400 cycles, a test 150, loads return out of order and the only wait is for all of them.
+    // takes such leaves through a loop with FOUR record sets: s[68:83] and s[84:99] hold records too, the traversal
+    // state that lives there waits in lanes 32 .. 44 of v61, s20 .. s23 are the leaf-relative indices of the records in
+    // the four sets, s[24:25] the triangles still to request, vcc_lo the leaf's first record.  Two records are tested
+    // while the next two are on their way: a scalar load takes such a wave about 400 cycles, a test 150, loads return
+    // out of order and the only wait is for all of them.
     if ((presorted || zpat != 0u) && FUSED && (rem & 0xffu) != 0u) {
       RtBundle bundle = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
       const uint32_t cull = (CULLABLE && cull_offset != 0u && wave_bundle(live, e, d, stop_t, bundle, cull_r0_max, cull_ksp_max)) ? cull_offset : 0u;
