@@ -153,6 +153,8 @@ __device__ __forceinline__ uint64_t walk_asm(const float4* nodes, uint32_t varia
   // (the loop with four record sets takes s[68:83] over while its leaf is open and puts the node array's address back
   //  afterwards: an operand that is written, like the rest of that range)
   uint64_t a_nodes = (uint64_t)(uintptr_t)nodes;
+  // (the record of the child to be tested next: requested inside the block, carried across the exact node test outside it)
+  uint64_t a_nx0 = 0ull, a_nx1 = 0ull, a_nx2 = 0ull, a_nx3 = 0ull;
   uint32_t a_work = 0u;   // triangles met in large leaves so far: the block treats a walk with many of them differently (see the register map at the call)
   const float cmax = rt_max3(fabsf(fc.x), fabsf(fc.y), fabsf(fc.z));
 #ifdef RT_WAVE_TIMES_CLK
@@ -175,7 +177,8 @@ __device__ __forceinline__ uint64_t walk_asm(const float4* nodes, uint32_t varia
             "+{s78}"(a_idx), "+{s79}"(a_rfirst), "+{s80}"(a_rmeta), "+{s[34:35]}"(a_acc), "+{s[96:97]}"(a_und), \
             "+{s30}"(a_res), "+{m0}"(a_sp) RT_COUNT_OPERAND, \
             "+{v60}"(st.first), "+{v61}"(st.cur), "+{v62}"(st.mask_lo), "+{v63}"(st.mask_hi), \
-            "+{s[82:83]}"(a_nodes), "+{s23}"(a_work), "+{v58}"(hit.t), [prim] "+v"(hit.prim)
+            "+{s[82:83]}"(a_nodes), "+{s23}"(a_work), "+{v58}"(hit.t), [prim] "+v"(hit.prim), \
+            "+{s[84:85]}"(a_nx0), "+{s[86:87]}"(a_nx1), "+{s[88:89]}"(a_nx2), "+{s[90:91]}"(a_nx3)
 #define RT_WALK_INPUTS \
             "{s[32:33]}"(a_tri), "{s18}"(zpat), "{v[40:41]}"(e_xy), "{v42}"(e.z), "{v[44:45]}"(c_zx), "{v[46:47]}"(c_yz), \
             "{v[48:49]}"(c_yx), "{v50}"(inv.x), "{v51}"(inv.y), "{v52}"(inv.z), "{v53}"(fc.x), "{v54}"(fc.y), "{v55}"(fc.z), "{v56}"(cmax), \
@@ -185,7 +188,7 @@ __device__ __forceinline__ uint64_t walk_asm(const float4* nodes, uint32_t varia
 #define RT_WALK_CLOBBERS \
             "s20", "s21", "s22", "s24", "s25", "s26", "s27", "s28", "s29", "s31", "s92", "s93", "s94", "s95", "s98", "s99", "s81", \
             "s36", "s37", "s38", "s39", "s40", "s41", "s42", "s43", "s44", "s45", "s46", "s47", "s48", "s49", "s50", "s51", "s52", "s53", "s54", "s55", \
-            "s56", "s57", "s58", "s59", "s60", "s61", "s62", "s63", "s64", "s65", "s66", "s67", "s84", "s85", "s86", "s87", "s88", "s89", "s90", "s91", \
+            "s56", "s57", "s58", "s59", "s60", "s61", "s62", "s63", "s64", "s65", "s66", "s67", \
             "v32", "v33", "v34", "v35", "v36", "v37", "v38", "v39", "v64", "v65", "v66", "v67", "v68", "v69", "v70", "v71", "v72", "v73", "v74", \
             "v75", "v76", "v77", "v78", "v79", "vcc", "scc", "memory"
   // (barycentrics in LDS: the wave's two columns, lane by lane; the block adds the lane's offset itself)

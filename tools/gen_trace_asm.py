@@ -753,10 +753,8 @@ def block(pattern, with_cull, bary):
     if BATCH:
         L += leaf_big(with_cull)
     L += finish(bary)
-    L += [# ---- re-entry: the record of the next sibling is requested again (its registers were not kept outside)
+    L += [# ---- re-entry (the record of the next sibling came along: s[84:91] are operands that the caller carries)
           "LT_resume_exact_%=:",
-          "s_lshl_b32 %s, %s, 5" % (OFF, IDX),
-          "s_load_dwordx8 s[84:91], %s, %s" % (BLK, OFF),
           "s_branch LT_after_exact_%=",
           "LT_exit_exact_%=:",
           "s_mov_b32 %s, 1" % RES,
