@@ -1077,6 +1077,9 @@ struct RtWaveArgs {
   // Tiles of the launch and how they are dealt to the chip's dies (see tile_of): tiles per row / column, strips of
   // RT_STRIP_W tile columns per die (0: a plain two-dimensional grid, one workgroup per tile)
   uint32_t tiles_x, tiles_y, strips_per_die, centre_first;
+  // ceil(2^32 / divisor) for the two divisions by launch constants that every wave makes (rows per band, tiles per strip):
+  // n / d = the high word of n * magic for every n the launch can ask about (checked on the host); 0: divide
+  uint32_t band_magic, strip_magic;
   RtQueues wf;
 };
 #define RT_WAVE_ARGS_OFFSET 16   // two pointers in front of the block
@@ -1160,13 +1163,19 @@ __global__ __launch_bounds__(RT_WBLOCK, !MESH ? (BOUNCE ? RT_WAVES_PER_SIMD_SPHE
   // the picture (ragged widths) has no tile: its lanes are invalid.  (Measured on the headline frame: 2.88 ms with a plain grid, 2.72 ms with the strips walked
   // row by row, 2.70 ms strip by strip; strips 2 or 8 columns wide and square blocks of 4 to 16 tiles: 2.71 to 2.84 ms.)
   struct Tile { uint32_t x, y; };
+  auto const_div = [](uint32_t n, uint32_t d, uint32_t magic) -> uint32_t { return magic ? __umulhi(n, magic) : n / d; };
+  auto band_row = [&](const RowMap& rows, int lrow) -> int {   // image row of local row lrow (rt_kernels.h, RowMap)
+    const int band = (int)const_div((uint32_t)lrow, (uint32_t)rows.band_rows, LATE(band_magic));
+    return rows.row0 + band * rows.band_stride + (lrow - band * rows.band_rows);
+  };
   auto tile_of = [&]() {
     Tile t = {blockIdx.x, blockIdx.y};
     const uint32_t spd = LATE(strips_per_die);
     if (spd != 0u) {
       const uint32_t die = blockIdx.x % RT_DIES, j = blockIdx.x / RT_DIES;
-      const uint32_t per_strip = RT_STRIP_W * LATE(tiles_y), in_strip = j % per_strip;
-      uint32_t strip = j / per_strip;
+      const uint32_t per_strip = RT_STRIP_W * LATE(tiles_y);
+      uint32_t strip = const_div(j, per_strip, LATE(strip_magic));
+      const uint32_t in_strip = j - strip * per_strip;
       if (LATE(centre_first)) { const uint32_t off = (strip + 1u) >> 1; strip = (strip & 1u) ? (spd >> 1) - off : (spd >> 1) + off; }
       t.y = in_strip / RT_STRIP_W;
       t.x = (strip * RT_DIES + die) * RT_STRIP_W + in_strip % RT_STRIP_W;
@@ -1187,7 +1196,7 @@ __global__ __launch_bounds__(RT_WBLOCK, !MESH ? (BOUNCE ? RT_WAVES_PER_SIMD_SPHE
       p.col = tile.x * RT_WTILE_W + (w % RT_WAVES_X) * 8 + (l & 7);
       p.lrow = tile.y * RT_WTILE_H + (w / RT_WAVES_X) * 8 + (l >> 3);
     }
-    p.row = rows.row0 + (p.lrow / rows.band_rows) * rows.band_stride + p.lrow % rows.band_rows;
+    p.row = band_row(rows, p.lrow);
     p.orow = rows.compact ? p.lrow : p.row;
     p.valid = p.col < W && p.lrow < rows.n_local && p.row < H && (!rows.small || l < 16);
     return p;
@@ -1567,16 +1576,16 @@ __global__ __launch_bounds__(RT_WBLOCK, !MESH ? (BOUNCE ? RT_WAVES_PER_SIMD_SPHE
     int wave = TID(); asm volatile("" : "+v"(wave)); wave >>= 6;
     if (pxe.valid) count(N_RAYS);   // the primary ray
     const int col0 = pxe.col & ~7, lrow0 = pxe.lrow & ~7;   // tile origin (wave-uniform)
-    const int last_row = rows.row0 + ((lrow0 + 7) / rows.band_rows) * rows.band_stride + (lrow0 + 7) % rows.band_rows;
+    const int first_row = band_row(rows, lrow0), last_row = band_row(rows, lrow0 + 7);
     const bool whole = !rows.small && (W & 3) == 0 && col0 + 8 <= W && lrow0 + 8 <= rows.n_local && last_row < H &&
-                       (lrow0 / rows.band_rows) == ((lrow0 + 7) / rows.band_rows);   // wave-uniform
+                       last_row == first_row + 7;   // (the tile's rows lie in one band; wave-uniform)
     if (whole) {
       uint8_t* pk = (uint8_t*)pack[wave];
       pk[LANE() * 3 + 0] = q[0]; pk[LANE() * 3 + 1] = q[1]; pk[LANE() * 3 + 2] = q[2];
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
       if (LANE() < 48) {
         const int r = LANE() / 6, j = LANE() - 6 * r;
-        const int orow0 = rows.compact ? lrow0 : (rows.row0 + (lrow0 / rows.band_rows) * rows.band_stride + lrow0 % rows.band_rows);
+        const int orow0 = rows.compact ? lrow0 : first_row;
         uint32_t* dst = (uint32_t*)(rgb + ((size_t)(orow0 + r) * W + col0) * 3) + j;
         *dst = pack[wave][r * 6 + j];
       }
@@ -1669,6 +1678,13 @@ void rt_launch_wave_kernel(const RtDeviceView& V, const RowMap& rows, bool bounc
   }
   RtWaveArgs A;
   A.tiles_x = grid.x; A.tiles_y = grid.y; A.strips_per_die = 0u;
+  // n / d as the high word of n * ceil(2^32 / d): exact for every n <= n_max when n_max * (ceil(2^32 / d) * d - 2^32) < 2^32
+  auto magic_for = [](uint64_t d, uint64_t n_max) -> uint32_t {
+    if (d < 2) return 0u;
+    const uint64_t m = ((1ull << 32) + d - 1) / d, e = m * d - (1ull << 32);
+    return (m >> 32) == 0 && n_max * e < (1ull << 32) ? (uint32_t)m : 0u;
+  };
+  A.band_magic = magic_for((uint64_t)rows.band_rows, (uint64_t)rows.n_local + 64u); A.strip_magic = 0u;
   static const bool strips_in_order = getenv("RT_AMD_STRIPS_IN_ORDER") != nullptr;   // measurements
   A.centre_first = strips_in_order ? 0u : 1u;
   static const bool plain_grid = getenv("RT_AMD_PLAIN_GRID") != nullptr;   // measurements
@@ -1685,6 +1701,7 @@ void rt_launch_wave_kernel(const RtDeviceView& V, const RowMap& rows, bool bounc
   if (!wf.in && RT_WBLOCK == 64 && !plain_grid && ((uint64_t)grid.x * grid.y >= strip_min_tiles || rows.strips)) {
     const uint32_t strips = (grid.x + RT_STRIP_W - 1u) / RT_STRIP_W;
     A.strips_per_die = (strips + RT_DIES - 1u) / RT_DIES;
+    A.strip_magic = magic_for((uint64_t)RT_STRIP_W * grid.y, (uint64_t)A.strips_per_die * RT_STRIP_W * grid.y + 1u);
     grid = dim3(RT_DIES * A.strips_per_die * RT_STRIP_W * grid.y, 1);
   }
   A.cam = V.cam; A.rows = rows; A.tri_geom = V.tri_geom; A.tri_shade = V.tri_shade;
