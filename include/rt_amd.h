@@ -68,7 +68,8 @@ typedef struct rt_stats {
   uint64_t wave_paths[8];
   float kernel_ms;   /* HIP-event time of the render kernels of this call (0 unless RT_RENDER_TIME) */
   float copy_ms;     /* rt_render_rows_host with RT_RENDER_TIME: the copy of the rows to host memory (main.cu:56-57) */
-  uint32_t from_queues;     /* 1: the bounce rays of this call went through queues, generation by generation */
+  uint32_t from_queues;     /* 1: the bounce rays of this call went through queues, generation by generation; 2: and twice - the
+                             * launches, sized by the longest generation of the context's frame before, were too short for this one */
   uint32_t queue_fallback;  /* 1: a queue or the term-slot pool was too small; the call was rendered on the stacks instead */
 } rt_stats;
 

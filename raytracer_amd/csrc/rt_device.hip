@@ -118,6 +118,8 @@ struct TermPool { size_t at = 0, bytes = 0; uint32_t tag = 0; };
 struct RenderCtx {
   Arena arena;
   WavefrontLayout wf_layout; bool wf_laid_out = false;
+  uint32_t wf_longest = 0u;   // rays of the longest generation of the last frame rendered from queues (0: none yet)
+  uint32_t wf_attempts = 0u;  // how many times the last frame from queues was rendered (2: its launches, sized by the frame before, were too short)
   TermPool own_pool; TermPool* pool = &own_pool;   // (the fixed arena's lives with the arena, not with the context)
   uint8_t* d_rgb = nullptr; int32_t* d_ids = nullptr; float* d_t = nullptr; size_t frame_px = 0;
   void* pinned = nullptr; size_t pinned_bytes = 0;
@@ -128,7 +130,7 @@ struct RenderCtx {
   RenderCtx& operator=(const RenderCtx&) = delete;
   void release() {
     if (!arena.fixed) (void)hipFree(arena.base);
-    arena = Arena(); own_pool = TermPool(); wf_laid_out = false;
+    arena = Arena(); own_pool = TermPool(); wf_laid_out = false; wf_longest = 0u;
     (void)hipFree(d_rgb); (void)hipFree(d_ids); (void)hipFree(d_t); d_rgb = nullptr; d_ids = nullptr; d_t = nullptr; frame_px = 0;
     if (pinned) (void)hipHostFree(pinned);
     pinned = nullptr; pinned_bytes = 0;
@@ -348,6 +350,10 @@ void slot_order(uint32_t slot, int depth, int D, int p, RtSlotOrder* o) {
 // *done = false: a queue or the block pool was too small; the caller renders the stacked way instead.
 // Everything is enqueued back to back - how many rays a generation holds stays on the device; the one read-back at the
 // end tells whether something overflowed.
+// The launches that render a queue are sized for the longest generation of the context's last frame and a margin (a full
+// queue when there was none): the 260 000 waves of a full queue at 3840x2160, of which a glass-bunny generation fills 19 000, take
+// 47 us to start and leave.  The device notes when a generation outgrew its launch; such a frame is rendered a second time with
+// launches for full queues.
 int render_wavefront(const SceneArrays& S, RenderCtx& ctx, const RowMap& rows, bool count, uint8_t* d_rgb, int32_t* d_ids, float* d_t, bool tally,
                      hipStream_t stream, bool* done) {
   *done = false;
@@ -362,17 +368,7 @@ int render_wavefront(const SceneArrays& S, RenderCtx& ctx, const RowMap& rows, b
     HIP_TRY(hipMemsetAsync(base + L.terms, 0, L.terms_bytes, stream));
     pool.at = L.terms; pool.bytes = L.terms_bytes; pool.tag = 0u;
   }
-  pool.tag++;
-  HIP_TRY(hipMemsetAsync(state, 0, sizeof(RtQState), stream));
-  RtQueues q;
-  memset(&q, 0, sizeof q);
-  q.in = nullptr; q.out = queue[0]; q.order = nullptr; q.state = state;
-  q.terms = (RtTermRGB*)(base + L.terms); q.block_pixel = (uint32_t*)(base + L.block_pixel);
-  q.in_index = 1u; q.out_index = 0u; q.queue_cap = L.queue_cap; q.block_cap = L.block_cap; q.pushes = (uint32_t)p; q.tag = pool.tag; q.enabled = 1;
   static const uint32_t small_below = getenv("RT_AMD_QUEUE_SMALL") ? (uint32_t)strtoul(getenv("RT_AMD_QUEUE_SMALL"), nullptr, 10) : RT_QUEUE_SMALL;   // measurements
-  q.small_below = small_below;
-  rt_launch_wave_kernel(S.view, rows, true, count, d_rgb, d_ids, d_t, counters, tally, q, stream);
-  HIP_TRY(hipGetLastError());
   static const bool sort_rays = !(getenv("RT_AMD_SORT_RAYS") && atoi(getenv("RT_AMD_SORT_RAYS")) == 0);   // measurements
   static const uint32_t octant_first_min = getenv("RT_AMD_OCTANT_FIRST_MIN") ? (uint32_t)strtoul(getenv("RT_AMD_OCTANT_FIRST_MIN"), nullptr, 10) : 600000u;
   // The order of a queue's rays: direction class first (the face of the cube around the origin a ray leaves through, 4 x 4 cells
@@ -383,36 +379,55 @@ int render_wavefront(const SceneArrays& S, RenderCtx& ctx, const RowMap& rows, b
   static const uint32_t dir_grid = getenv("RT_AMD_SORT_DIRGRID") ? (uint32_t)strtoul(getenv("RT_AMD_SORT_DIRGRID"), nullptr, 10) : 4u;
   static const uint32_t cell_bits = getenv("RT_AMD_SORT_CELLBITS") ? (uint32_t)strtoul(getenv("RT_AMD_SORT_CELLBITS"), nullptr, 10) : 4u;
   if (dir_grid && ((unsigned long long)6 * dir_grid * dir_grid << (3u * cell_bits)) > RT_QBINS) { rt_set_error("RT_AMD_SORT_DIRGRID / RT_AMD_SORT_CELLBITS: more bins than the sort has"); return RT_ERR_ARG; }
-  uint32_t cur = 0u;
-  for (int gen = 1; gen <= D; gen++) {   // rays of depth `gen` (camera.cu:104-112 works them off one by one)
-    rt_launch_queue_advance(state, cur ^ 1u, stream);
-    q.in = queue[cur]; q.in_index = cur; q.out = queue[cur ^ 1u]; q.out_index = cur ^ 1u; q.order = nullptr;
-    if (sort_rays && S.view.has_oct) {   // the queue is put in an order that keeps similar rays together
-      uint32_t* const order = (uint32_t*)(base + L.order);
-      rt_launch_ray_order(queue[cur], state, cur, L.queue_cap, octant_first_min, dir_grid, cell_bits, (uint32_t*)(base + L.keys), (uint32_t*)(base + L.bins),
-                          (uint32_t*)(base + L.sums), order, stream);
-      q.order = order;
-    }
-#ifdef RT_WAVE_TIMES
-    rt_launch_wave_kernel(S.view, rows, true, count, nullptr, nullptr, d_t, counters, tally, q, stream);   // (diagnostic build: the waves log their lives there)
-#else
-    rt_launch_wave_kernel(S.view, rows, true, count, nullptr, nullptr, nullptr, counters, tally, q, stream);
-#endif
-    HIP_TRY(hipGetLastError());
-    cur ^= 1u;
-  }
+  static const bool full_launches = getenv("RT_AMD_QUEUE_FULL_LAUNCHES") != nullptr;   // measurements
   RtSlotOrder order; order.n = 0u;
   slot_order(0u, 0, D, p, &order);
-  rt_launch_resolve_blocks(q, order, d_rgb, stream);
-  HIP_TRY(hipGetLastError());
   RtQState h_pageable;
   // (a context with page-locked landing words keeps the queue state behind the counters' place there)
   RtQState* const h = ctx.landing ? (RtQState*)((unsigned char*)ctx.landing + RT_COUNTER_BYTES) : &h_pageable;
-  HIP_TRY(hipMemcpyAsync(h, state, sizeof(RtQState), hipMemcpyDeviceToHost, stream));
-  HIP_TRY(hipStreamSynchronize(stream));
-  if (h->overflow || h->n_blocks > L.block_cap || h->count[0] > L.queue_cap || h->count[1] > L.queue_cap) return RT_OK;
-  *done = true;
-  return RT_OK;
+  for (int attempt = 0; attempt < 2; attempt++) {
+    unsigned long long cover = L.queue_cap;
+    if (attempt == 0 && ctx.wf_longest && !full_launches) cover = std::min<unsigned long long>(cover, (unsigned long long)ctx.wf_longest + ctx.wf_longest / 4u + 65536ull);
+    pool.tag++;
+    HIP_TRY(hipMemsetAsync(state, 0, sizeof(RtQState), stream));
+    RtQueues q;
+    memset(&q, 0, sizeof q);
+    q.in = nullptr; q.out = queue[0]; q.order = nullptr; q.state = state;
+    q.terms = (RtTermRGB*)(base + L.terms); q.block_pixel = (uint32_t*)(base + L.block_pixel);
+    q.in_index = 1u; q.out_index = 0u; q.queue_cap = L.queue_cap; q.block_cap = L.block_cap; q.pushes = (uint32_t)p; q.tag = pool.tag; q.enabled = 1;
+    q.small_below = small_below; q.launch_rays = (uint32_t)cover;
+    rt_launch_wave_kernel(S.view, rows, true, count, d_rgb, d_ids, d_t, counters, tally, q, stream);
+    HIP_TRY(hipGetLastError());
+    uint32_t cur = 0u;
+    for (int gen = 1; gen <= D; gen++) {   // rays of depth `gen` (camera.cu:104-112 works them off one by one)
+      rt_launch_queue_advance(state, cur ^ 1u, q.launch_rays, stream);
+      q.in = queue[cur]; q.in_index = cur; q.out = queue[cur ^ 1u]; q.out_index = cur ^ 1u; q.order = nullptr;
+      if (sort_rays && S.view.has_oct) {   // the queue is put in an order that keeps similar rays together
+        uint32_t* const ray_order = (uint32_t*)(base + L.order);
+        rt_launch_ray_order(queue[cur], state, cur, L.queue_cap, octant_first_min, dir_grid, cell_bits, (uint32_t*)(base + L.keys), (uint32_t*)(base + L.bins),
+                            (uint32_t*)(base + L.sums), ray_order, stream);
+        q.order = ray_order;
+      }
+#ifdef RT_WAVE_TIMES
+      rt_launch_wave_kernel(S.view, rows, true, count, nullptr, nullptr, d_t, counters, tally, q, stream);   // (diagnostic build: the waves log their lives there)
+#else
+      rt_launch_wave_kernel(S.view, rows, true, count, nullptr, nullptr, nullptr, counters, tally, q, stream);
+#endif
+      HIP_TRY(hipGetLastError());
+      cur ^= 1u;
+    }
+    rt_launch_resolve_blocks(q, order, d_rgb, stream);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipMemcpyAsync(h, state, sizeof(RtQState), hipMemcpyDeviceToHost, stream));
+    HIP_TRY(hipStreamSynchronize(stream));
+    if (h->overflow || h->n_blocks > L.block_cap || h->count[0] > L.queue_cap || h->count[1] > L.queue_cap) return RT_OK;
+    ctx.wf_longest = h->longest; ctx.wf_attempts = (uint32_t)attempt + 1u;
+    if (!h->grid_short) { *done = true; return RT_OK; }
+    // (the counters of the instrumented variant would hold both attempts; the tests that read them render on a context's first frame)
+    if (count || tally) HIP_TRY(hipMemsetAsync(counters, 0, RT_COUNTER_BYTES, stream));
+  }
+  rt_set_error("a frame rendered with launches for full queues reports a generation longer than a queue");
+  return RT_ERR_DEVICE;
 }
 
 // The render proper; the device of the scene is current.  `timed` needs two events (created here, destroyed on every way
@@ -493,7 +508,7 @@ int launch_render(const SceneArrays& S, RenderCtx& ctx, RowMap rows, uint8_t* d_
     stats->ub_level_overflow = h[C_UB_OVER]; stats->ub_stack_overflow = h[C_UB_STACK];
     stats->rays_traced = (flags & RT_RENDER_LITERAL) ? h[C_RAYS] : h[C_TRACED]; stats->kernel_ms = ms;
     for (int k = 0; k < 8; k++) stats->wave_paths[k] = h[C_W_TRACE + k];
-    stats->from_queues = used_queues ? 1u : 0u; stats->queue_fallback = fell_back ? 1u : 0u;
+    stats->from_queues = used_queues ? ctx.wf_attempts : 0u; stats->queue_fallback = fell_back ? 1u : 0u;
   }
   return RT_OK;
 }

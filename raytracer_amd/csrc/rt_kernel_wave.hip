@@ -1305,7 +1305,9 @@ __global__ __launch_bounds__(RT_WBLOCK, !MESH ? (BOUNCE ? RT_WAVES_PER_SIMD_SPHE
   };
 
   // A launch that renders a queue: one chunk of the queue per wave.  How long the queue is, is only known on the device; the
-  // launch has a wave for every chunk of a full queue, and a wave whose chunk lies beyond the queue's end leaves at once.
+  // launch has a wave for every chunk of a queue as long as the host expects at most (a full queue on a context's first frame,
+  // the last frame's longest generation and a margin afterwards; a frame whose queue turns out longer is rendered again), and a
+  // wave whose chunk lies beyond the queue's end leaves at once.
   // (Waves that stay and take chunk after chunk by ticket were measured too: the glass bunny at 4K took 7.6 ms that way
   // against 5.3 ms, at 1920x1080 3.8 against 3.2 ms.)
   if (queued) {
@@ -1671,9 +1673,10 @@ void rt_launch_wave_kernel(const RtDeviceView& V, const RowMap& rows, bool bounc
   const int tw = rows.small ? RT_WTILE_W / 2 : RT_WTILE_W, th = rows.small ? RT_WTILE_H / 2 : RT_WTILE_H;
   dim3 grid((V.cam.width + tw - 1) / tw, (rows.n_local + th - 1) / th), block(RT_WBLOCK);
   if (wf.in) {
-    // one chunk per wave, for as many chunks as a full queue has (of a short queue, cut into chunks of 16 rays, only
+    // one chunk per wave, for as many chunks as a queue of wf.launch_rays rays has (of a short queue, cut into chunks of 16 rays, only
     // RT_QUEUE_SMALL / 16 exist); a wave whose chunk lies beyond the queue's end leaves at once
-    const uint32_t chunks = wf.queue_cap < wf.small_below ? (wf.queue_cap + 15u) / 16u : std::max(wf.small_below / 16u, (wf.queue_cap + 63u) / 64u);
+    const uint32_t cover = wf.launch_rays;
+    const uint32_t chunks = cover < wf.small_below ? (cover + 15u) / 16u : std::max(wf.small_below / 16u, (cover + 63u) / 64u);
     grid = dim3((chunks + RT_WBLOCK / 64 - 1) / (RT_WBLOCK / 64), 1); bounce = true;
   }
   RtWaveArgs A;

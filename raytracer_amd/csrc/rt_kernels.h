@@ -93,10 +93,11 @@ struct RtTermRGB { float r, g, b; uint32_t tag; };
 struct RtQState {     // device-resident bookkeeping of a frame rendered from queues
   uint32_t count[2];  // rays in queue 0 / 1 (may exceed the capacity: then `overflow` is set)
   uint32_t n_blocks;  // term blocks handed out
-  uint32_t unused;
+  uint32_t longest;   // rays of the frame's longest generation so far
   uint32_t overflow;  // a queue or the block pool was full
   uint32_t box_lo[3], box_hi[3];   // box around the origins of the queue about to be rendered (floats in an order-preserving code)
-  uint32_t pad[5];
+  uint32_t grid_short;   // a generation held more rays than its launch had waves for: the frame is not complete
+  uint32_t pad[4];
 };
 static_assert(sizeof(RtQState) == 64, "queue state");
 #define RT_TERM_SLOTS_MAX 128u   // nodes of a pixel's ray tree beyond which bounce rays stay on the lanes' stacks
@@ -113,6 +114,7 @@ struct RtQueues {
   uint32_t pushes;                        // P: most rays one hit can push (the fan-out of the slot numbering)
   uint32_t tag;                           // of this frame's terms
   uint32_t small_below;                   // queues shorter than this are rendered with 16 rays per wave instead of 64
+  uint32_t launch_rays;                   // the launch that renders `in` has waves for so many rays (<= queue_cap)
   int32_t enabled;
 };
 // Order in which a block's slots are added up: depth first, later pushes first (the LIFO stack's order); n <= RT_TERM_SLOTS_MAX.
@@ -251,7 +253,7 @@ void rt_launch_ray_order(const RtQRay* rays, RtQState* state, uint32_t in_index,
                          uint32_t* keys, uint32_t* bins, uint32_t* sums, uint32_t* order, hipStream_t stream);
 // Between two generations: the queue that was just rendered becomes the next output queue (its count is cleared), the
 // box around the origins is emptied.
-void rt_launch_queue_advance(RtQState* state, uint32_t clear_index, hipStream_t stream);
+void rt_launch_queue_advance(RtQState* state, uint32_t clear_index, uint32_t launch_rays, hipStream_t stream);
 // Adds up the valid slots of every block in the stack's order, quantises and stores the pixel.
 void rt_launch_resolve_blocks(const RtQueues& q, const RtSlotOrder& order, uint8_t* rgb, hipStream_t stream);
 

@@ -213,7 +213,11 @@ __global__ __launch_bounds__(QBLOCK) void q_scatter(const RtQState* __restrict__
   }
 }
 
-__global__ void q_advance(RtQState* state, uint32_t clear_index) {
+// Between two launches of a frame: the queue that was filled is about to be rendered by a launch with waves for `launch_rays` rays.
+__global__ void q_advance(RtQState* state, uint32_t clear_index, uint32_t launch_rays) {
+  const uint32_t n = state->count[clear_index ^ 1u];
+  if (n > state->longest) state->longest = n;
+  if (n > launch_rays) state->grid_short = 1u;
   state->count[clear_index] = 0u;
   for (int k = 0; k < 3; k++) { state->box_lo[k] = 0xffffffffu; state->box_hi[k] = 0u; }
 }
@@ -256,8 +260,8 @@ int rt_preload_queue_kernels() {
   return (int)e;
 }
 
-void rt_launch_queue_advance(RtQState* state, uint32_t clear_index, hipStream_t stream) {
-  hipLaunchKernelGGL(q_advance, dim3(1), dim3(1), 0, stream, state, clear_index);
+void rt_launch_queue_advance(RtQState* state, uint32_t clear_index, uint32_t launch_rays, hipStream_t stream) {
+  hipLaunchKernelGGL(q_advance, dim3(1), dim3(1), 0, stream, state, clear_index, launch_rays);
 }
 
 void rt_launch_resolve_blocks(const RtQueues& q, const RtSlotOrder& order, uint8_t* rgb, hipStream_t stream) {

@@ -611,3 +611,25 @@ def test_skipping_triangles_from_random_viewpoints(tmp_path):
             seen += int((ida >= 0).mean() > 0.05)   # (a twentieth of the pixels or more show a triangle)
             ds.close()
     assert seen >= 10
+
+
+@pytest.mark.gpu
+def test_queue_launches_sized_by_the_frame_before():
+    # The launches that render a queue have waves for the longest generation of the context's last frame and a margin.  A frame
+    # whose generations outgrow that is noticed on the device and rendered again with launches for full queues: same bytes, ids
+    # and counts as on a fresh context, whatever the context rendered before.
+    w, h = 1920, 1080
+    sc = rt.Scene("scenes/meshTransparentBunny.json", w, h, 3)
+    fresh = rt.DeviceScene(sc)
+    want, wid, _, sw = fresh.render_host(flags=rt.RT_RENDER_QUEUED)
+    assert sw["from_queues"] == 1 and sw["rays"] > w * h + 200000
+    ds = rt.DeviceScene(sc)
+    rows = np.flatnonzero((wid >= 0).any(axis=1))
+    few, fid, _, sf = ds.render_host(int(rows[0]), int(rows[0]) + 2, flags=rt.RT_RENDER_QUEUED)      # the bunny's topmost rows: a handful of bounce rays
+    assert sf["from_queues"] == 1 and np.array_equal(few[rows[0]:rows[0] + 2], want[rows[0]:rows[0] + 2]) and sf["rays"] > 2 * w
+    got, gid, _, sg = ds.render_host(flags=rt.RT_RENDER_QUEUED)        # launches sized for that handful: too short
+    again, aid, _, sa = ds.render_host(flags=rt.RT_RENDER_QUEUED)      # sized by the whole frame: enough
+    assert (sg["from_queues"], sa["from_queues"]) == (2, 1)
+    assert np.array_equal(got, want) and np.array_equal(again, want) and np.array_equal(gid, wid) and np.array_equal(aid, wid)
+    for k in ("rays", "shadow_rays", "rays_traced"):
+        assert sg[k] == sw[k] == sa[k], (k, sg[k], sw[k], sa[k])
