@@ -5,6 +5,8 @@
 // stride over them, so a frame's launches are enqueued without the host ever learning a count.
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
+
 #include "rt_kernels.h"
 
 namespace {
@@ -30,37 +32,43 @@ __device__ __forceinline__ uint32_t ray_count(const RtQState* state, uint32_t in
 // pushed by neighbouring pixels and mostly share their cell, and a counter that every ray of a queue hit on its own
 // would serialise at the memory side.  Returns, for a scatter, the position the lane's ray gets (base of the run that
 // the first lane of the group reserved + the lane's rank in the group) when `want_pos` is set.
+// The groups are found first, with ballots alone; then the first lanes of ALL groups send their additions in one
+// instruction.  An addition whose result is needed is a round trip to the memory side (the counters are shared by
+// the dies), well over a microsecond; one after the other, group by group, that was what the scatter's time consisted of.
 __device__ __forceinline__ uint32_t grouped_add(uint32_t* counters, uint32_t key, bool active, bool want_pos) {
   const int lane = (int)(threadIdx.x & 63u);
   uint64_t todo = __builtin_amdgcn_ballot_w64(active);
-  uint32_t pos = 0u;
+  uint32_t rank = 0u, size = 0u;
+  int first = lane;
   while (todo) {
     const int leader = __builtin_ctzll(todo);
     const uint32_t k = (uint32_t)__builtin_amdgcn_readlane((int)key, leader);
     const uint64_t same = __builtin_amdgcn_ballot_w64(active && key == k);
-    uint32_t base = 0u;
-    if (lane == leader) base = atomicAdd(&counters[k], (uint32_t)__builtin_popcountll(same));
-    if (want_pos) {
-      base = (uint32_t)__builtin_amdgcn_readlane((int)base, leader);
-      if (active && key == k) pos = base + (uint32_t)__builtin_popcountll(same & ((1ull << lane) - 1ull));
-    }
+    if (active && key == k) { first = leader; rank = (uint32_t)__builtin_popcountll(same & ((1ull << lane) - 1ull)); size = (uint32_t)__builtin_popcountll(same); }
     todo &= ~same;
   }
-  return pos;
+  uint32_t base = 0u;
+  if (active && first == lane) base = atomicAdd(&counters[key], size);
+  if (!want_pos) return 0u;
+  base = (uint32_t)__shfl((int)base, first, 64);
+  return base + rank;
 }
 
 // Floats as unsigned integers of the same order (for atomicMin / atomicMax).
 __device__ __forceinline__ uint32_t ordered(float f) { const uint32_t b = __float_as_uint(f); return (b & 0x80000000u) ? ~b : (b | 0x80000000u); }
 __device__ __forceinline__ float unordered(uint32_t u) { return __uint_as_float((u & 0x80000000u) ? (u & 0x7fffffffu) : ~u); }
 
-// Pass 0: the box around the rays' origins (the grid of the keys is laid over it: however large the scene, the cells
-// are a 64th of what the rays of this generation span).
+// Pass 0: the box around the rays' origins, or around a sample of them (the grid of the keys is laid over it: however large
+// the scene, the cells are a 16th of what the rays of this generation span).
 constexpr uint32_t BGRID = 256;
 __global__ __launch_bounds__(QBLOCK) void q_bounds(const RtQRay* __restrict__ rays, RtQState* __restrict__ state, uint32_t in_index, uint32_t queue_cap) {
   const uint32_t n = ray_count(state, in_index, queue_cap);
   if (n < RT_QUEUE_SORT_MIN) return;
   uint32_t lo[3] = {0xffffffffu, 0xffffffffu, 0xffffffffu}, hi[3] = {0u, 0u, 0u};
-  for (uint32_t i = blockIdx.x * QBLOCK + threadIdx.x; i < n; i += BGRID * QBLOCK)
+  // Every ray costs the pass a 64-byte line for its 12 bytes of origin (1.2 M rays: 77 MB, 19 us), and the box only places a grid
+  // whose border cells take whatever lies outside: of a long queue every eighth ray is looked at.
+  const uint32_t step = n >= 65536u ? 8u : 1u;
+  for (uint32_t i = (blockIdx.x * QBLOCK + threadIdx.x) * step; i < n; i += BGRID * QBLOCK * step)
     for (int k = 0; k < 3; k++) {
       const float e = rays[i].e[k];
       if (e - e == 0.f) { const uint32_t u = ordered(e); lo[k] = u < lo[k] ? u : lo[k]; hi[k] = u > hi[k] ? u : hi[k]; }   // (finite ones)
@@ -152,7 +160,7 @@ __global__ __launch_bounds__(QBLOCK) void q_scan_blocks(const uint32_t* __restri
   if (threadIdx.x == 0) sums[b] = part[0];
 }
 
-__global__ __launch_bounds__(1024) void q_scan_sums(uint32_t* __restrict__ sums) {
+__global__ __launch_bounds__(1024) void q_scan_sums(uint32_t* __restrict__ sums, uint32_t blocks) {
   // RT_QBIN_BLOCKS values, 1024 threads: each thread owns a run of consecutive values
   __shared__ uint32_t part[1024];
   constexpr uint32_t PER = (RT_QBIN_BLOCKS + 1023u) / 1024u;
@@ -160,7 +168,7 @@ __global__ __launch_bounds__(1024) void q_scan_sums(uint32_t* __restrict__ sums)
   uint32_t s = 0u;
   for (uint32_t k = 0; k < PER; k++) {
     const uint32_t i = threadIdx.x * PER + k;
-    local[k] = i < RT_QBIN_BLOCKS ? sums[i] : 0u;
+    local[k] = i < blocks ? sums[i] : 0u;
     s += local[k];
   }
   part[threadIdx.x] = s;
@@ -174,7 +182,7 @@ __global__ __launch_bounds__(1024) void q_scan_sums(uint32_t* __restrict__ sums)
   uint32_t run = part[threadIdx.x] - s;
   for (uint32_t k = 0; k < PER; k++) {
     const uint32_t i = threadIdx.x * PER + k;
-    if (i < RT_QBIN_BLOCKS) sums[i] = run;
+    if (i < blocks) sums[i] = run;
     run += local[k];
   }
 }
@@ -245,11 +253,14 @@ __global__ __launch_bounds__(QBLOCK) void q_resolve(const RtQState* __restrict__
 void rt_launch_ray_order(const RtQRay* rays, RtQState* state, uint32_t in_index, uint32_t queue_cap, uint32_t octant_first_min, uint32_t dir_grid, uint32_t cell_bits,
                          uint32_t* keys, uint32_t* bins, uint32_t* sums, uint32_t* order, hipStream_t stream) {
   hipLaunchKernelGGL(q_bounds, dim3(BGRID), dim3(QBLOCK), 0, stream, rays, state, in_index, queue_cap);
-  (void)hipMemsetAsync(bins, 0, (size_t)RT_QBINS * sizeof(uint32_t), stream);
+  // (only the blocks of bins that this order's keys reach are cleared and summed: 393 216 of 2 M with the default grids)
+  const uint64_t used = dir_grid ? ((uint64_t)6 * dir_grid * dir_grid << (3u * cell_bits)) : (uint64_t)RT_QBINS;
+  const uint32_t blocks = (uint32_t)std::min<uint64_t>(RT_QBIN_BLOCKS, (used + RT_QBIN_BLOCK - 1u) / RT_QBIN_BLOCK);
+  (void)hipMemsetAsync(bins, 0, (size_t)blocks * RT_QBIN_BLOCK * sizeof(uint32_t), stream);
   hipLaunchKernelGGL(q_keys, dim3(QGRID), dim3(QBLOCK), 0, stream, rays, (const RtQState*)state, in_index, queue_cap, octant_first_min, dir_grid, cell_bits, keys, bins);
-  hipLaunchKernelGGL(q_scan_blocks, dim3(RT_QBIN_BLOCKS), dim3(QBLOCK), 0, stream, bins, sums);
-  hipLaunchKernelGGL(q_scan_sums, dim3(1), dim3(1024), 0, stream, sums);
-  hipLaunchKernelGGL(q_scan_bins, dim3(RT_QBIN_BLOCKS), dim3(QBLOCK), 0, stream, bins, sums);
+  hipLaunchKernelGGL(q_scan_blocks, dim3(blocks), dim3(QBLOCK), 0, stream, bins, sums);
+  hipLaunchKernelGGL(q_scan_sums, dim3(1), dim3(1024), 0, stream, sums, blocks);
+  hipLaunchKernelGGL(q_scan_bins, dim3(blocks), dim3(QBLOCK), 0, stream, bins, sums);
   hipLaunchKernelGGL(q_scatter, dim3(QGRID), dim3(QBLOCK), 0, stream, (const RtQState*)state, in_index, queue_cap, keys, bins, order);
 }
 
