@@ -5,6 +5,9 @@ kernel identical to the oracle's (the traversal takes the same decisions node by
 within 1 LSB on at least 99.9 % of pixels (device powf/expf/pow differ from glibc's by ulps).
 """
 import hashlib
+import os
+import subprocess
+import sys
 
 import numpy as np
 import pytest
@@ -613,7 +616,6 @@ def test_skipping_triangles_from_random_viewpoints(tmp_path):
     assert seen >= 10
 
 
-@pytest.mark.gpu
 def test_queue_launches_sized_by_the_frame_before():
     # The launches that render a queue have waves for the longest generation of the context's last frame and a margin.  A frame
     # whose generations outgrow that is noticed on the device and rendered again with launches for full queues: same bytes, ids
@@ -633,3 +635,27 @@ def test_queue_launches_sized_by_the_frame_before():
     assert np.array_equal(got, want) and np.array_equal(again, want) and np.array_equal(gid, wid) and np.array_equal(aid, wid)
     for k in ("rays", "shadow_rays", "rays_traced"):
         assert sg[k] == sw[k] == sa[k], (k, sg[k], sw[k], sa[k])
+
+
+def test_the_order_of_a_queue_never_shows_in_the_image():
+    # The order in which a generation's rays are rendered is a matter of speed only: every ray writes its own term slot.  The
+    # settings are read once per process, so each one renders in a process of its own; the digest of bytes, ids and counts
+    # must be the one of the default order (direction class and 16^3 cells), also without any order, with the octant order
+    # (whose keys use all 2 M bins where the default uses 393 216) and with other grids.
+    code = ("import hashlib, raytracer_amd as rt\n"
+            "ds = rt.DeviceScene(rt.Scene('scenes/meshTransparentBunny.json', 640, 360, 3))\n"
+            "for _ in range(2):\n"
+            "    rgb, ids, ts, st = ds.render_host(flags=rt.RT_RENDER_QUEUED)\n"
+            "    assert st['from_queues'] == 1\n"
+            "    print(hashlib.sha256(rgb.tobytes() + ids.tobytes() + ts.tobytes()).hexdigest(), st['rays'], st['shadow_rays'])\n")
+    seen = {}
+    for setting in ({}, {"RT_AMD_SORT_RAYS": "0"}, {"RT_AMD_SORT_DIRGRID": "0"}, {"RT_AMD_SORT_DIRGRID": "6", "RT_AMD_SORT_CELLBITS": "3"},
+                    {"RT_AMD_SORT_DIRGRID": "2", "RT_AMD_SORT_CELLBITS": "5"}, {"RT_AMD_QUEUE_FULL_LAUNCHES": "1"}, {"RT_AMD_QUEUE_SMALL": "1000"}):
+        env = dict(os.environ, **setting)
+        out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=300,
+                             cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+        assert out.returncode == 0, (setting, out.stderr[-2000:])
+        lines = [l for l in out.stdout.splitlines() if len(l.split()) == 3]
+        assert len(lines) == 2 and lines[0] == lines[1], (setting, out.stdout)
+        seen[tuple(sorted(setting.items()))] = lines[0]
+    assert len(set(seen.values())) == 1, seen
