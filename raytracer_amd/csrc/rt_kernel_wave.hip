@@ -1461,11 +1461,17 @@ __global__ __launch_bounds__(RT_WBLOCK, !MESH ? (BOUNCE ? RT_WAVES_PER_SIMD_SPHE
             }
             sh.li++; continue;
           }
-          RtVec3 l; float ldist;
-          if (L.type == RT_DIRECTIONAL) { l = {L.dir[0] * -1, L.dir[1] * -1, L.dir[2] * -1}; ldist = RT_INF; }
-          else l = rt_normalized({L.pos[0] - P.x, L.pos[1] - P.y, L.pos[2] - P.z});
-          const RtVec3 sP = {P.x + l.x * RT_EPS, P.y + l.y * RT_EPS, P.z + l.z * RT_EPS};
-          if (L.type != RT_DIRECTIONAL) ldist = rt_len({L.pos[0] - sP.x, L.pos[1] - sP.y, L.pos[2] - sP.z});
+          RtVec3 l, sP; float ldist;
+          if (MESH && verdict >= 0) {
+            // the step comes round again with the verdict of the trace it asked for: the direction to the light is the ray's,
+            // worked out then (a root and three divisions for a point light), and its origin and length have served
+            l = tr_d; sP = tr_e; ldist = tr_stop;
+          } else {
+            if (L.type == RT_DIRECTIONAL) { l = {L.dir[0] * -1, L.dir[1] * -1, L.dir[2] * -1}; ldist = RT_INF; }
+            else l = rt_normalized({L.pos[0] - P.x, L.pos[1] - P.y, L.pos[2] - P.z});
+            sP = {P.x + l.x * RT_EPS, P.y + l.y * RT_EPS, P.z + l.z * RT_EPS};
+            if (L.type != RT_DIRECTIONAL) ldist = rt_len({L.pos[0] - sP.x, L.pos[1] - sP.y, L.pos[2] - sP.z});
+          }
           if (LATE_AT(ka, cam).shadows) {   // ray.cu:56-72
             bool occluded;
             if (verdict >= 0) {   // the trace requested by this very step has come back
